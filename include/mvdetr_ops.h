@@ -1,0 +1,118 @@
+/* mvdetr_ops.h -- C ABI of libmvdetr_ops.so: the MI355X (gfx950) kernels of MVDeTr's multiview
+ * ground-plane fusion path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one host launcher of the reference's
+ * CUDA extension (paths relative to the reference checkout), keeps that launcher's argument
+ * order and meaning, and differs from it only in returning the HIP error code instead of
+ * printf-ing it (ms_deform_im2col_cuda.cuh:948-952, 1321-1325 swallow launch failures).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (including spatial_shapes / level_start_index, which the
+ *     reference also reads on the device: ms_deform_attn_cuda.cu:67-68); no host copies, no
+ *     synchronisation, no allocation: work is enqueued on `stream` and the call returns.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - tensors are dense row-major with the shapes given below; fp32 (`_f32`) or fp64 (`_f64`),
+ *     like AT_DISPATCH_FLOATING_TYPES in ms_deform_attn_cuda.cu:64,134.
+ *   - return value: 0 (hipSuccess) or a hipError_t; 1 (hipErrorInvalidValue) for bad arguments.
+ *   - thread-safe and re-entrant: the only global state is the forward-variant knob below
+ *     (an atomic int, initialised from the environment variable MVDETR_MSDA_FWD_IMPL).
+ */
+#ifndef MVDETR_OPS_H
+#define MVDETR_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVDETR_OPS_ABI_VERSION 1
+
+/* ABI version of the loaded library (checked by the Python loader). */
+int mvdetr_ops_abi_version(void);
+
+/* ---- Multi-scale deformable attention, forward ------------------------------------------------
+ * Replaces ms_deformable_im2col_cuda (ms_deform_im2col_cuda.cuh:923-954) and the kernel it
+ * launches (cuh:237-299, device helper cuh:33-84).
+ *   value            [batch, spatial_size, num_heads, channels]
+ *   spatial_shapes   [num_levels, 2]  int64 (H_l, W_l)
+ *   level_start_index[num_levels]     int64, token offset of level l inside spatial_size
+ *   sampling_loc     [batch, num_query, num_heads, num_levels, num_point, 2]  (x, y) in [0,1]
+ *   attn_weight      [batch, num_query, num_heads, num_levels, num_point]
+ *   out              [batch, num_query, num_heads*channels]   (every element is written)
+ */
+int mvdetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const float *sampling_loc,
+                            const float *attn_weight, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point, float *out);
+int mvdetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const double *sampling_loc,
+                            const double *attn_weight, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point, double *out);
+
+/* ---- Multi-scale deformable attention, backward -----------------------------------------------
+ * Replaces ms_deformable_col2im_cuda (ms_deform_im2col_cuda.cuh:956-1327) and its six kernel
+ * variants (cuh:301-920, device helpers cuh:87-234).
+ *   grad_col          [batch, num_query, num_heads*channels]   upstream gradient
+ *   grad_value        same shape as value; MUST BE ZERO on entry (accumulated with atomics,
+ *                     like the reference: ms_deform_attn_cuda.cu:121)
+ *   grad_sampling_loc same shape as sampling_loc; fully written
+ *   grad_attn_weight  same shape as attn_weight; fully written
+ */
+int mvdetr_msda_backward_f32(void *stream, const float *grad_col, const float *value,
+                             const int64_t *spatial_shapes, const int64_t *level_start_index,
+                             const float *sampling_loc, const float *attn_weight, int batch,
+                             int spatial_size, int num_heads, int channels, int num_levels,
+                             int num_query, int num_point, float *grad_value,
+                             float *grad_sampling_loc, float *grad_attn_weight);
+int mvdetr_msda_backward_f64(void *stream, const double *grad_col, const double *value,
+                             const int64_t *spatial_shapes, const int64_t *level_start_index,
+                             const double *sampling_loc, const double *attn_weight, int batch,
+                             int spatial_size, int num_heads, int channels, int num_levels,
+                             int num_query, int num_point, double *grad_value,
+                             double *grad_sampling_loc, double *grad_attn_weight);
+
+/* ---- Feature -> ground-plane homography warp ---------------------------------------------------
+ * Replaces the third-party call kornia.warp_perspective(src, M, dsize, mode='bilinear',
+ * padding_mode='zeros', align_corners=False) at multiview_detector/models/mvdetr.py:194-195
+ * (kornia: normalize_homography -> inverse -> transform_points(meshgrid) -> F.grid_sample),
+ * fused into one kernel.
+ *   src  [n, channels, src_h, src_w]        (NCHW, like the reference's imgs_feat)
+ *   M    [n, 3, 3]  destination pixel <- source pixel homography, same dtype as src
+ *   dst  [n, channels, dst_h, dst_w]        every element is written (zeros outside the view)
+ * `layout_nhwc` != 0 writes dst as [n, dst_h, dst_w, channels] instead (the token layout the
+ * shadow transformer consumes, trans_world_feat.py:92), saving the permute copy.
+ */
+int mvdetr_warp_perspective_forward_f32(void *stream, const float *src, const float *M, int n,
+                                        int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                        int layout_nhwc, float *dst);
+int mvdetr_warp_perspective_forward_f64(void *stream, const double *src, const double *M, int n,
+                                        int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                        int layout_nhwc, double *dst);
+
+/* Gradient of the warp w.r.t. src (what autograd reaches through grid_sample in the reference).
+ *   grad_dst [n, channels, dst_h, dst_w] (or NHWC if layout_nhwc)
+ *   grad_src [n, channels, src_h, src_w]; MUST BE ZERO on entry (accumulated with atomics)
+ */
+int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, const float *M, int n,
+                                         int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                         int layout_nhwc, float *grad_src);
+int mvdetr_warp_perspective_backward_f64(void *stream, const double *grad_dst, const double *M,
+                                         int n, int channels, int src_h, int src_w, int dst_h,
+                                         int dst_w, int layout_nhwc, double *grad_src);
+
+/* ---- Introspection (used by bench.py / tests, not by the model code) ---------------------------
+ * Name of the kernel variant the last forward call ON THIS THREAD dispatched to
+ * ("gather", "tile16", ...).  Static storage; never NULL. */
+const char *mvdetr_msda_last_forward_impl(void);
+
+/* Forward kernel variant selection: 0 = auto (default; tiled LDS kernel where it applies, else
+ * the gather kernel), 1 = always gather, 2 = tile whenever the shape supports it.  Results are
+ * identical up to fp32 summation order; this is a tuning/testing knob.  Returns the previous value.
+ * Initial value comes from MVDETR_MSDA_FWD_IMPL = auto | gather | tile. */
+int mvdetr_msda_set_forward_impl(int impl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVDETR_OPS_H */

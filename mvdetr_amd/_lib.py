@@ -1,0 +1,93 @@
+"""ctypes binding of libmvdetr_ops.so (C ABI in include/mvdetr_ops.h).
+
+There is NO fallback: if the shared library is missing or does not export the expected symbols
+the import of the op layer raises, and calling an op with CPU tensors raises like the reference
+extension does (ms_deform_attn.h:38 "Not implemented on the CPU").
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime this library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
+ABI_VERSION = 1
+
+_vp, _i = ctypes.c_void_p, ctypes.c_int
+_MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
+_MSDA_BWD = [_vp] * 7 + [_i] * 7 + [_vp] * 3
+_WARP = [_vp] * 3 + [_i] * 7 + [_vp]
+
+SIGNATURES = {
+    "mvdetr_ops_abi_version": ([], _i),
+    "mvdetr_msda_last_forward_impl": ([], ctypes.c_char_p),
+    "mvdetr_msda_set_forward_impl": ([_i], _i),
+    "mvdetr_msda_forward_f32": (_MSDA_FWD, _i),
+    "mvdetr_msda_forward_f64": (_MSDA_FWD, _i),
+    "mvdetr_msda_backward_f32": (_MSDA_BWD, _i),
+    "mvdetr_msda_backward_f64": (_MSDA_BWD, _i),
+    "mvdetr_warp_perspective_forward_f32": (_WARP, _i),
+    "mvdetr_warp_perspective_forward_f64": (_WARP, _i),
+    "mvdetr_warp_perspective_backward_f32": (_WARP, _i),
+    "mvdetr_warp_perspective_backward_f64": (_WARP, _i),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libmvdetr_ops.so failed:\n" + res.stdout)
+    if verbose:
+        print(res.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C mvdetr_amd/csrc`). "
+                "There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise ImportError(f"{LIB_PATH} does not export {name}") from e
+            fn.argtypes, fn.restype = argtypes, restype
+        got = handle.mvdetr_ops_abi_version()
+        if got != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION} (stale build?)")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    """Launch failures raise (the reference only printf's them, cuh:948-952)."""
+    if rc != 0:
+        name = "hipErrorInvalidValue" if rc == 1 else f"hipError {rc}"
+        raise RuntimeError(f"{what} failed: {name}")
+
+
+def current_stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def suffix(dtype) -> str:
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    # AT_DISPATCH_FLOATING_TYPES in the reference: float and double only (ms_deform_attn_cuda.cu:64)
+    raise RuntimeError(f'"mvdetr_ops" not implemented for \'{dtype}\'')

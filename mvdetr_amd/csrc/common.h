@@ -1,0 +1,86 @@
+// Shared helpers for the gfx950 kernels of libmvdetr_ops.so (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MVDETR_WAVE 64
+
+namespace mvdetr {
+
+template <typename T, int N> struct VecOf;
+template <> struct VecOf<float, 1> { using type = float; };
+template <> struct VecOf<float, 2> { using type = float2; };
+template <> struct VecOf<float, 4> { using type = float4; };
+template <> struct VecOf<double, 1> { using type = double; };
+template <> struct VecOf<double, 2> { using type = double2; };
+
+// N consecutive scalars, loaded/stored with one 4/8/16-byte access when N > 1.
+template <typename T, int N> struct Pack {
+    T v[N];
+    __device__ __forceinline__ static Pack load(const T *p) {
+        Pack r;
+        if constexpr (N == 1) {
+            r.v[0] = *p;
+        } else {
+            using V = typename VecOf<T, N>::type;
+            V t = *reinterpret_cast<const V *>(p);
+            const T *e = reinterpret_cast<const T *>(&t);
+#pragma unroll
+            for (int i = 0; i < N; ++i) r.v[i] = e[i];
+        }
+        return r;
+    }
+    __device__ __forceinline__ void store(T *p) const {
+        if constexpr (N == 1) {
+            *p = v[0];
+        } else {
+            using V = typename VecOf<T, N>::type;
+            V t;
+            T *e = reinterpret_cast<T *>(&t);
+#pragma unroll
+            for (int i = 0; i < N; ++i) e[i] = v[i];
+            *reinterpret_cast<V *>(p) = t;
+        }
+    }
+    __device__ __forceinline__ static Pack zero() {
+        Pack r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = T(0);
+        return r;
+    }
+};
+
+__device__ __forceinline__ float ffloor(float x) { return floorf(x); }
+__device__ __forceinline__ double ffloor(double x) { return floor(x); }
+
+// Bilinear footprint of one sampling point in one level: integer corner, fractional weights and
+// per-corner validity (zero padding).  (h, w) are already in pixel units: loc*size - 0.5, the
+// align_corners=False convention of grid_sample and of ms_deform_im2col_cuda.cuh:285-286.
+template <typename T> struct Footprint {
+    int y0, x0;
+    T wy0, wy1, wx0, wx1;
+    bool vy0, vy1, vx0, vx1;
+};
+
+template <typename T>
+__device__ __forceinline__ Footprint<T> footprint(T h, T w, int H, int W) {
+    Footprint<T> f;
+    T fy = ffloor(h), fx = ffloor(w);
+    f.y0 = (int)fy;
+    f.x0 = (int)fx;
+    f.wy1 = h - fy;
+    f.wx1 = w - fx;
+    f.wy0 = T(1) - f.wy1;
+    f.wx0 = T(1) - f.wx1;
+    f.vy0 = f.y0 >= 0 && f.y0 < H;
+    f.vy1 = f.y0 + 1 >= 0 && f.y0 + 1 < H;
+    f.vx0 = f.x0 >= 0 && f.x0 < W;
+    f.vx1 = f.x0 + 1 >= 0 && f.x0 + 1 < W;
+    return f;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace mvdetr

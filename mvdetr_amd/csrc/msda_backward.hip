@@ -1,0 +1,230 @@
+// Multi-scale deformable attention, backward -- gfx950 (MI355X) kernels + C ABI.
+//
+// Replaces ms_deformable_col2im_cuda and its six kernel variants
+// (multiview_detector/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:956-1327, 301-920) and the
+// device helpers ms_deform_attn_col2im_bilinear{,_gm} (cuh:87-234).
+//
+// The reference picks among shared-memory reductions by block size because its block IS the D
+// channels of one (b,q,head) (16 threads at MVDeTr's D=16: a quarter of a wave64).  Here:
+//   msda_bwd_lanes<T, VEC, G>  G = D/VEC lanes (power of two <= 64) own one (b,q,head); the
+//                              per-tap partial sums for grad_sampling_loc / grad_attn_weight are
+//                              reduced across those G lanes with DPP/xor shuffles inside the wave
+//                              -- no LDS, no barrier -- and lane 0 of the group stores them.
+//   msda_bwd_serial<T>         any D: one lane per (b,q,head) walks the channels itself.
+// grad_value is accumulated with hardware fp atomics (global_atomic_add_f32/f64,
+// -munsafe-fp-atomics), i.e. the summation order -- like the reference's atomicAdd
+// (cuh:125-152) -- is not deterministic.
+#include "common.h"
+#include "../../include/mvdetr_ops.h"
+
+namespace mvdetr {
+
+template <typename T> __device__ __forceinline__ void atomic_add(T *p, T v) { atomicAdd(p, v); }
+
+template <typename T, int G> __device__ __forceinline__ T group_sum(T v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+
+template <typename T, int VEC, int G>
+__global__ __launch_bounds__(256) void msda_bwd_lanes(
+    const T *__restrict__ grad_col, const T *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const T *__restrict__ loc, const T *__restrict__ aw, int B, int S,
+    int M, int D, int L, int Lq, int P, T *__restrict__ grad_value, T *__restrict__ grad_loc,
+    T *__restrict__ grad_aw)
+{
+    // all G lanes of a group stay converged (same (b,q,m) => same branch decisions), which is what
+    // makes the shuffles below legal
+    const int64_t total = (int64_t)B * Lq * M * G;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = idx < total;
+    const int64_t cidx = live ? idx : total - 1;
+    const int cg = (int)(cidx % G);
+    const int64_t bqm = cidx / G;
+    const int m = (int)(bqm % M);
+    const int64_t bq = bqm / M;
+    const int b = (int)(bq / Lq);
+    const int64_t row = (int64_t)M * D;
+    const T *lp = loc + bqm * L * P * 2;
+    const T *wp = aw + bqm * L * P;
+    const int64_t voff = (int64_t)b * S * row + (int64_t)m * D + cg * VEC;
+    const Pack<T, VEC> go = Pack<T, VEC>::load(grad_col + bqm * D + cg * VEC);
+    for (int l = 0; l < L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const int64_t poff = voff + lsi[l] * row;
+        for (int p = 0; p < P; ++p) {
+            const int t = l * P + p;
+            const T x = lp[t * 2 + 0] * T(W) - T(0.5);
+            const T y = lp[t * 2 + 1] * T(H) - T(0.5);
+            const T a = wp[t];
+            T g_a = 0, g_x = 0, g_y = 0;
+            if (y > T(-1) && x > T(-1) && y < T(H) && x < T(W)) {
+                const Footprint<T> f = footprint(y, x, H, W);
+                const int64_t o00 = poff + ((int64_t)f.y0 * W + f.x0) * row;
+                const int64_t o01 = o00 + row, o10 = o00 + (int64_t)W * row, o11 = o10 + row;
+                const bool v00 = f.vy0 && f.vx0, v01 = f.vy0 && f.vx1;
+                const bool v10 = f.vy1 && f.vx0, v11 = f.vy1 && f.vx1;
+                Pack<T, VEC> c00 = Pack<T, VEC>::zero(), c01 = c00, c10 = c00, c11 = c00;
+                if (v00) c00 = Pack<T, VEC>::load(value + o00);
+                if (v01) c01 = Pack<T, VEC>::load(value + o01);
+                if (v10) c10 = Pack<T, VEC>::load(value + o10);
+                if (v11) c11 = Pack<T, VEC>::load(value + o11);
+                const T w00 = f.wy0 * f.wx0, w01 = f.wy0 * f.wx1, w10 = f.wy1 * f.wx0, w11 = f.wy1 * f.wx1;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const T g = go.v[i];
+                    g_a += g * (w00 * c00.v[i] + w01 * c01.v[i] + w10 * c10.v[i] + w11 * c11.v[i]);
+                    g_x += g * ((c01.v[i] - c00.v[i]) * f.wy0 + (c11.v[i] - c10.v[i]) * f.wy1);
+                    g_y += g * ((c10.v[i] - c00.v[i]) * f.wx0 + (c11.v[i] - c01.v[i]) * f.wx1);
+                    if (live) {
+                        const T ga = g * a;
+                        if (v00) atomic_add(grad_value + o00 + i, w00 * ga);
+                        if (v01) atomic_add(grad_value + o01 + i, w01 * ga);
+                        if (v10) atomic_add(grad_value + o10 + i, w10 * ga);
+                        if (v11) atomic_add(grad_value + o11 + i, w11 * ga);
+                    }
+                }
+            }
+            g_a = group_sum<T, G>(g_a);
+            g_x = group_sum<T, G>(g_x);
+            g_y = group_sum<T, G>(g_y);
+            if (live && cg == 0) {
+                grad_aw[bqm * L * P + t] = g_a;
+                grad_loc[(bqm * L * P + t) * 2 + 0] = T(W) * a * g_x;
+                grad_loc[(bqm * L * P + t) * 2 + 1] = T(H) * a * g_y;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void msda_bwd_serial(
+    const T *__restrict__ grad_col, const T *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const T *__restrict__ loc, const T *__restrict__ aw, int B, int S,
+    int M, int D, int L, int Lq, int P, T *__restrict__ grad_value, T *__restrict__ grad_loc,
+    T *__restrict__ grad_aw)
+{
+    const int64_t total = (int64_t)B * Lq * M;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t row = (int64_t)M * D;
+    for (int64_t bqm = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; bqm < total; bqm += stride) {
+        const int m = (int)(bqm % M);
+        const int64_t bq = bqm / M;
+        const int b = (int)(bq / Lq);
+        const T *go = grad_col + bqm * D;
+        const int64_t voff = (int64_t)b * S * row + (int64_t)m * D;
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            const int64_t poff = voff + lsi[l] * row;
+            for (int p = 0; p < P; ++p) {
+                const int64_t t = bqm * L * P + l * P + p;
+                const T x = loc[t * 2 + 0] * T(W) - T(0.5);
+                const T y = loc[t * 2 + 1] * T(H) - T(0.5);
+                const T a = aw[t];
+                T g_a = 0, g_x = 0, g_y = 0;
+                if (y > T(-1) && x > T(-1) && y < T(H) && x < T(W)) {
+                    const Footprint<T> f = footprint(y, x, H, W);
+                    const int64_t o00 = poff + ((int64_t)f.y0 * W + f.x0) * row;
+                    const int64_t o01 = o00 + row, o10 = o00 + (int64_t)W * row, o11 = o10 + row;
+                    const bool v00 = f.vy0 && f.vx0, v01 = f.vy0 && f.vx1;
+                    const bool v10 = f.vy1 && f.vx0, v11 = f.vy1 && f.vx1;
+                    const T w00 = f.wy0 * f.wx0, w01 = f.wy0 * f.wx1, w10 = f.wy1 * f.wx0, w11 = f.wy1 * f.wx1;
+                    for (int c = 0; c < D; ++c) {
+                        const T g = go[c], ga = g * a;
+                        const T c00 = v00 ? value[o00 + c] : T(0), c01 = v01 ? value[o01 + c] : T(0);
+                        const T c10 = v10 ? value[o10 + c] : T(0), c11 = v11 ? value[o11 + c] : T(0);
+                        g_a += g * (w00 * c00 + w01 * c01 + w10 * c10 + w11 * c11);
+                        g_x += g * ((c01 - c00) * f.wy0 + (c11 - c10) * f.wy1);
+                        g_y += g * ((c10 - c00) * f.wx0 + (c11 - c01) * f.wx1);
+                        if (v00) atomic_add(grad_value + o00 + c, w00 * ga);
+                        if (v01) atomic_add(grad_value + o01 + c, w01 * ga);
+                        if (v10) atomic_add(grad_value + o10 + c, w10 * ga);
+                        if (v11) atomic_add(grad_value + o11 + c, w11 * ga);
+                    }
+                }
+                grad_aw[t] = g_a;
+                grad_loc[t * 2 + 0] = T(W) * a * g_x;
+                grad_loc[t * 2 + 1] = T(H) * a * g_y;
+            }
+        }
+    }
+}
+
+#define MSDA_BWD_ARGS grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, grad_value, grad_loc, grad_aw
+
+template <typename T, int VEC, int G>
+static int launch_lanes(hipStream_t st, const T *grad_col, const T *value, const int64_t *shapes,
+                        const int64_t *lsi, const T *loc, const T *aw, int B, int S, int M, int D, int L,
+                        int Lq, int P, T *grad_value, T *grad_loc, T *grad_aw)
+{
+    const int64_t total = (int64_t)B * Lq * M * G;
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((msda_bwd_lanes<T, VEC, G>), dim3((unsigned)blocks), dim3(256), 0, st, MSDA_BWD_ARGS);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int backward_entry(void *stream, const T *grad_col, const T *value, const int64_t *shapes,
+                          const int64_t *lsi, const T *loc, const T *aw, int B, int S, int M, int D, int L,
+                          int Lq, int P, T *grad_value, T *grad_loc, T *grad_aw)
+{
+    if (B < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0) return (int)hipErrorInvalidValue;
+    if ((int64_t)B * Lq == 0) return 0;
+    if (!grad_col || !value || !shapes || !lsi || !loc || !aw || !grad_value || !grad_loc || !grad_aw)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    const bool a16 = aligned(value, 16) && aligned(grad_col, 16);
+    if (a16 && D % WIDE == 0) {
+        switch (D / WIDE) {
+        case 1: return launch_lanes<T, WIDE, 1>(st, MSDA_BWD_ARGS);
+        case 2: return launch_lanes<T, WIDE, 2>(st, MSDA_BWD_ARGS);
+        case 4: return launch_lanes<T, WIDE, 4>(st, MSDA_BWD_ARGS);
+        case 8: return launch_lanes<T, WIDE, 8>(st, MSDA_BWD_ARGS);
+        case 16: return launch_lanes<T, WIDE, 16>(st, MSDA_BWD_ARGS);
+        case 32: return launch_lanes<T, WIDE, 32>(st, MSDA_BWD_ARGS);
+        case 64: return launch_lanes<T, WIDE, 64>(st, MSDA_BWD_ARGS);
+        default: break;
+        }
+    }
+    const int64_t total = (int64_t)B * Lq * M;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    hipLaunchKernelGGL((msda_bwd_serial<T>), dim3((unsigned)blocks), dim3(256), 0, st, MSDA_BWD_ARGS);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mvdetr
+
+extern "C" {
+
+int mvdetr_msda_backward_f32(void *stream, const float *grad_col, const float *value,
+                             const int64_t *spatial_shapes, const int64_t *level_start_index,
+                             const float *sampling_loc, const float *attn_weight, int batch,
+                             int spatial_size, int num_heads, int channels, int num_levels,
+                             int num_query, int num_point, float *grad_value,
+                             float *grad_sampling_loc, float *grad_attn_weight)
+{
+    return mvdetr::backward_entry<float>(stream, grad_col, value, spatial_shapes, level_start_index,
+                                         sampling_loc, attn_weight, batch, spatial_size, num_heads,
+                                         channels, num_levels, num_query, num_point, grad_value,
+                                         grad_sampling_loc, grad_attn_weight);
+}
+
+int mvdetr_msda_backward_f64(void *stream, const double *grad_col, const double *value,
+                             const int64_t *spatial_shapes, const int64_t *level_start_index,
+                             const double *sampling_loc, const double *attn_weight, int batch,
+                             int spatial_size, int num_heads, int channels, int num_levels,
+                             int num_query, int num_point, double *grad_value,
+                             double *grad_sampling_loc, double *grad_attn_weight)
+{
+    return mvdetr::backward_entry<double>(stream, grad_col, value, spatial_shapes, level_start_index,
+                                          sampling_loc, attn_weight, batch, spatial_size, num_heads,
+                                          channels, num_levels, num_query, num_point, grad_value,
+                                          grad_sampling_loc, grad_attn_weight);
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// Internal dispatch between the forward kernel variants (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvdetr {
+
+enum class MsdaFwdImpl { Gather, Tile };
+
+// fp32 LDS-tiled encoder kernel (msda_forward_tile.hip).  Only valid when
+// msda_fwd_choose_impl() returned Tile.
+int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                      const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
+                      int P, float *out);
+inline int msda_forward_tile(hipStream_t, const double *, const int64_t *, const int64_t *,
+                             const double *, const double *, int, int, int, int, int, int, int,
+                             double *)
+{
+    return 1;  // never chosen for fp64
+}
+
+// MVDETR_MSDA_FWD_IMPL = auto (default) | gather | tile; overridable at run time through
+// mvdetr_msda_set_forward_impl().
+int msda_fwd_impl_knob();
+
+bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16);
+
+template <typename T>
+inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *aw, const T *out, int B,
+                                        int S, int M, int D, int L, int Lq, int P)
+{
+    if (sizeof(T) != 4) return MsdaFwdImpl::Gather;
+    const int env = msda_fwd_impl_knob();
+    if (env == 1) return MsdaFwdImpl::Gather;
+    const bool a16 = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(loc) |
+                       reinterpret_cast<uintptr_t>(aw) | reinterpret_cast<uintptr_t>(out)) % 16) == 0;
+    if (!msda_tile_supported(B, S, M, D, L, Lq, P, a16)) return MsdaFwdImpl::Gather;
+    return MsdaFwdImpl::Tile;
+}
+
+}  // namespace mvdetr

@@ -1,0 +1,184 @@
+// Multi-scale deformable attention, forward -- gfx950 (MI355X) kernels + C ABI.
+//
+// Replaces ms_deformable_im2col_cuda / ms_deformable_im2col_gpu_kernel of the reference
+// (multiview_detector/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:923-954, 237-299, 33-84).
+// Written for wave64 / CDNA4 from the operation's definition; not derived from the CUDA source.
+//
+// Kernels
+//   msda_fwd_gather<T, VEC>   any shape/dtype.  One lane owns VEC consecutive channels of one
+//                             (b, q, head); the D/VEC lanes of a head read one contiguous
+//                             D*sizeof(T) segment per bilinear corner straight from L2/HBM.
+//   (the LDS-tiled encoder kernel lives in msda_forward_tile.hip)
+#include "common.h"
+#include "../../include/mvdetr_ops.h"
+#include "msda_dispatch.h"
+#include <atomic>
+#include <stdlib.h>
+#include <string.h>
+
+namespace mvdetr {
+
+static int impl_from_env()
+{
+    const char *e = getenv("MVDETR_MSDA_FWD_IMPL");
+    if (e && !strcmp(e, "gather")) return 1;
+    if (e && !strcmp(e, "tile")) return 2;
+    return 0;
+}
+
+static std::atomic<int> g_impl_knob{-1};
+
+int msda_fwd_impl_knob()
+{
+    int v = g_impl_knob.load(std::memory_order_relaxed);
+    if (v < 0) {
+        v = impl_from_env();
+        int expect = -1;
+        g_impl_knob.compare_exchange_strong(expect, v);
+        v = g_impl_knob.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void msda_fwd_gather(
+    const T *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const T *__restrict__ loc, const T *__restrict__ aw,
+    int B, int S, int M, int D, int L, int Lq, int P, T *__restrict__ out)
+{
+    const int groups = D / VEC;                          // lanes per (b,q,m)
+    const int64_t total = (int64_t)B * Lq * M * groups;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t row = (int64_t)M * D;                  // elements per value token
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int cg = (int)(idx % groups);
+        const int64_t bqm = idx / groups;
+        const int m = (int)(bqm % M);
+        const int64_t bq = bqm / M;
+        const int b = (int)(bq / Lq);
+        const T *lp = loc + bqm * L * P * 2;
+        const T *wp = aw + bqm * L * P;
+        const T *vb = value + (int64_t)b * S * row + (int64_t)m * D + cg * VEC;
+        Pack<T, VEC> acc = Pack<T, VEC>::zero();
+        for (int l = 0; l < L; ++l) {
+            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+            const T *plane = vb + lsi[l] * row;
+            for (int p = 0; p < P; ++p) {
+                const T x = lp[(l * P + p) * 2 + 0] * T(W) - T(0.5);
+                const T y = lp[(l * P + p) * 2 + 1] * T(H) - T(0.5);
+                const T a = wp[l * P + p];
+                if (!(y > T(-1) && x > T(-1) && y < T(H) && x < T(W))) continue;
+                const Footprint<T> f = footprint(y, x, H, W);
+                const T *r0 = plane + ((int64_t)f.y0 * W + f.x0) * row;
+                const T *r1 = r0 + (int64_t)W * row;
+                Pack<T, VEC> c00 = Pack<T, VEC>::zero(), c01 = c00, c10 = c00, c11 = c00;
+                if (f.vy0 && f.vx0) c00 = Pack<T, VEC>::load(r0);
+                if (f.vy0 && f.vx1) c01 = Pack<T, VEC>::load(r0 + row);
+                if (f.vy1 && f.vx0) c10 = Pack<T, VEC>::load(r1);
+                if (f.vy1 && f.vx1) c11 = Pack<T, VEC>::load(r1 + row);
+                const T w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a;
+                const T w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i)
+                    acc.v[i] += w00 * c00.v[i] + w01 * c01.v[i] + w10 * c10.v[i] + w11 * c11.v[i];
+            }
+        }
+        acc.store(out + bqm * D + cg * VEC);
+    }
+}
+
+template <typename T, int VEC>
+static int launch_gather(hipStream_t st, const T *value, const int64_t *shapes, const int64_t *lsi,
+                         const T *loc, const T *aw, int B, int S, int M, int D, int L, int Lq, int P,
+                         T *out)
+{
+    const int64_t total = (int64_t)B * Lq * M * (D / VEC);
+    const int block = 256;
+    int64_t blocks = (total + block - 1) / block;
+    if (blocks > (1 << 20)) blocks = 1 << 20;            // grid-stride beyond that
+    hipLaunchKernelGGL((msda_fwd_gather<T, VEC>), dim3((unsigned)blocks), dim3(block), 0, st, value,
+                       shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int msda_forward_gather(hipStream_t st, const T *value, const int64_t *shapes, const int64_t *lsi,
+                        const T *loc, const T *aw, int B, int S, int M, int D, int L, int Lq, int P,
+                        T *out)
+{
+    constexpr int WIDE = 16 / (int)sizeof(T);            // 4 floats / 2 doubles per 16-byte access
+    const bool a16 = aligned(value, 16) && aligned(out, 16);
+    if (a16 && D % WIDE == 0)
+        return launch_gather<T, WIDE>(st, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out);
+    return launch_gather<T, 1>(st, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out);
+}
+
+template int msda_forward_gather<float>(hipStream_t, const float *, const int64_t *, const int64_t *,
+                                        const float *, const float *, int, int, int, int, int, int, int,
+                                        float *);
+template int msda_forward_gather<double>(hipStream_t, const double *, const int64_t *, const int64_t *,
+                                         const double *, const double *, int, int, int, int, int, int,
+                                         int, double *);
+
+static thread_local const char *g_last_impl = "none";
+
+static bool bad_dims(int B, int S, int M, int D, int L, int Lq, int P)
+{
+    return B < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0;
+}
+
+template <typename T>
+static int forward_entry(void *stream, const T *value, const int64_t *shapes, const int64_t *lsi,
+                         const T *loc, const T *aw, int B, int S, int M, int D, int L, int Lq, int P,
+                         T *out)
+{
+    if (bad_dims(B, S, M, D, L, Lq, P)) return (int)hipErrorInvalidValue;
+    if ((int64_t)B * Lq == 0) { g_last_impl = "empty"; return 0; }     // nothing to write
+    if (!value || !shapes || !lsi || !loc || !aw || !out) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const MsdaFwdImpl impl = msda_fwd_choose_impl<T>(value, loc, aw, out, B, S, M, D, L, Lq, P);
+    if (impl == MsdaFwdImpl::Tile) {
+        g_last_impl = "tile";
+        return msda_forward_tile(st, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out);
+    }
+    g_last_impl = "gather";
+    return msda_forward_gather<T>(st, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out);
+}
+
+}  // namespace mvdetr
+
+extern "C" {
+
+int mvdetr_ops_abi_version(void) { return MVDETR_OPS_ABI_VERSION; }
+
+const char *mvdetr_msda_last_forward_impl(void) { return mvdetr::g_last_impl; }
+
+int mvdetr_msda_set_forward_impl(int impl)
+{
+    if (impl < 0 || impl > 2) impl = 0;
+    const int prev = mvdetr::msda_fwd_impl_knob();
+    mvdetr::g_impl_knob.store(impl);
+    return prev;
+}
+
+int mvdetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const float *sampling_loc,
+                            const float *attn_weight, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point, float *out)
+{
+    return mvdetr::forward_entry<float>(stream, value, spatial_shapes, level_start_index, sampling_loc,
+                                        attn_weight, batch, spatial_size, num_heads, channels,
+                                        num_levels, num_query, num_point, out);
+}
+
+int mvdetr_msda_forward_f64(void *stream, const double *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const double *sampling_loc,
+                            const double *attn_weight, int batch, int spatial_size, int num_heads,
+                            int channels, int num_levels, int num_query, int num_point, double *out)
+{
+    return mvdetr::forward_entry<double>(stream, value, spatial_shapes, level_start_index, sampling_loc,
+                                         attn_weight, batch, spatial_size, num_heads, channels,
+                                         num_levels, num_query, num_point, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// Feature -> ground-plane homography warp -- gfx950 (MI355X) kernels + C ABI.
+//
+// Replaces the reference's third-party call
+//     kornia.warp_perspective(imgs_feat, proj_mats, Rworld_shape, align_corners=False)
+// (multiview_detector/models/mvdetr.py:194-195), which kornia (0.5.x) evaluates as three torch
+// ops: normalize_homography + inverse on the 3x3s, transform_points over a normalised meshgrid
+// (materialising a [N,H,W,2] grid), and F.grid_sample(bilinear, zeros).  Here it is ONE kernel:
+// the 3x3 algebra and the per-pixel source coordinate are evaluated in fp64 registers from the
+// caller's matrix (exact w.r.t. kornia's formula on the same inputs -- the fp32 op chain itself
+// is only accurate to ~2e-4 near the horizon), the bilinear blend runs in the
+// tensor dtype, and pixels whose footprint misses the source image are stored as zeros without
+// touching `src`.
+//
+// Work mapping (wave64): a block is 64 consecutive destination pixels (lanes = pixels, so both the
+// source gathers and the NCHW stores are coalesced along x) times a group of up to 64 channels
+// split over the block's 4 waves.  For the channel-last output the 64x64 tile is transposed
+// through LDS (65-float rows, conflict-free both ways) so the stores are 256-byte rows.
+#include "common.h"
+#include "../../include/mvdetr_ops.h"
+
+namespace mvdetr {
+
+constexpr int WARP_PIX = 64;      // pixels per block (one per lane)
+constexpr int WARP_CH = 64;       // channels per block
+constexpr int WARP_SUB = 4;       // waves per block; each owns WARP_CH / WARP_SUB channels
+
+struct SrcCoord {
+    int y0, x0;
+    float wy0, wy1, wx0, wx1;    // blend weights (tensor dtype is applied by the caller)
+    bool v00, v01, v10, v11;
+    bool any;
+};
+
+// Source sampling position of destination pixel (i, j) under kornia's convention.
+template <typename T>
+__device__ __forceinline__ void source_position(const T *__restrict__ Mn, int i, int j, int h, int w,
+                                                double &x, double &y)
+{
+    // true inverse of the dst<-src homography, in fp64
+    const double m0 = Mn[0], m1 = Mn[1], m2 = Mn[2], m3 = Mn[3], m4 = Mn[4], m5 = Mn[5], m6 = Mn[6],
+                 m7 = Mn[7], m8 = Mn[8];
+    const double c0 = m4 * m8 - m5 * m7, c1 = m5 * m6 - m3 * m8, c2 = m3 * m7 - m4 * m6;
+    const double r = 1.0 / (m0 * c0 + m1 * c1 + m2 * c2);
+    const double dj = (double)j, di = (double)i;
+    // p = M^-1 (j, i, 1): source pixel, homogeneous
+    const double px = (c0 * dj + (m2 * m7 - m1 * m8) * di + (m1 * m5 - m2 * m4)) * r;
+    const double py = (c1 * dj + (m0 * m8 - m2 * m6) * di + (m2 * m3 - m0 * m5)) * r;
+    const double pz = (c2 * dj + (m1 * m6 - m0 * m7) * di + (m0 * m4 - m1 * m3)) * r;
+    // kornia normalises source pixels with the corner-aligned map 2p/(size-1) - 1 ...
+    const double wd = w == 1 ? 1e-14 : (double)(w - 1), hd = h == 1 ? 1e-14 : (double)(h - 1);
+    const double qx = 2.0 * px / wd - pz, qy = 2.0 * py / hd - pz;
+    // ... divides only where |z| > 1e-8 (convert_points_from_homogeneous) ...
+    const double s = fabs(pz) > 1e-8 ? 1.0 / pz : 1.0;
+    // ... and hands the result to an align_corners=False sampler: ((g + 1) * size - 1) / 2
+    x = ((qx * s + 1.0) * (double)w - 1.0) * 0.5;
+    y = ((qy * s + 1.0) * (double)h - 1.0) * 0.5;
+}
+
+__device__ __forceinline__ SrcCoord make_coord(double x, double y, int h, int w)
+{
+    SrcCoord c;
+    // reject far-out / non-finite positions before the int conversion
+    const bool in = x > -1.0 && y > -1.0 && x < (double)w && y < (double)h;
+    const double fx = floor(x), fy = floor(y);
+    c.x0 = in ? (int)fx : 0;
+    c.y0 = in ? (int)fy : 0;
+    c.wx1 = (float)(x - fx);
+    c.wy1 = (float)(y - fy);
+    c.wx0 = 1.0f - c.wx1;
+    c.wy0 = 1.0f - c.wy1;
+    const bool vx0 = c.x0 >= 0, vx1 = c.x0 + 1 < w, vy0 = c.y0 >= 0, vy1 = c.y0 + 1 < h;
+    c.v00 = in && vy0 && vx0;
+    c.v01 = in && vy0 && vx1;
+    c.v10 = in && vy1 && vx0;
+    c.v11 = in && vy1 && vx1;
+    c.any = c.v00 || c.v01 || c.v10 || c.v11;
+    return c;
+}
+
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
+    const T *__restrict__ src, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
+    T *__restrict__ dst)
+{
+    __shared__ float tile[NHWC && sizeof(T) == 4 ? WARP_PIX * (WARP_CH + 1) : 1];
+    const int lane = threadIdx.x & (WARP_PIX - 1);
+    const int sub = threadIdx.x / WARP_PIX;
+    const int64_t npix = (int64_t)N * H * W;
+    const int64_t pix = (int64_t)blockIdx.x * WARP_PIX + lane;
+    const int cbase = blockIdx.y * WARP_CH;
+    constexpr int CPT = WARP_CH / WARP_SUB;
+    const bool live = pix < npix;
+    int n = 0, i = 0, j = 0;
+    SrcCoord sc;
+    sc.any = false;
+    if (live) {
+        n = (int)(pix / ((int64_t)H * W));
+        const int rem = (int)(pix - (int64_t)n * H * W);
+        i = rem / W;
+        j = rem - i * W;
+        double x, y;
+        source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
+        sc = make_coord(x, y, h, w);
+    }
+    const T w00 = T(sc.wy0) * T(sc.wx0), w01 = T(sc.wy0) * T(sc.wx1);
+    const T w10 = T(sc.wy1) * T(sc.wx0), w11 = T(sc.wy1) * T(sc.wx1);
+    const int64_t plane = (int64_t)h * w;
+    const int64_t o00 = (int64_t)sc.y0 * w + sc.x0;
+#pragma unroll 4
+    for (int k = 0; k < CPT; ++k) {
+        const int c = cbase + sub * CPT + k;
+        T val = T(0);
+        if (live && c < C && sc.any) {
+            const T *sp = src + ((int64_t)n * C + c) * plane + o00;
+            const T a = sc.v00 ? sp[0] : T(0);
+            const T b = sc.v01 ? sp[1] : T(0);
+            const T cc = sc.v10 ? sp[w] : T(0);
+            const T d = sc.v11 ? sp[w + 1] : T(0);
+            val = w00 * a + w01 * b + w10 * cc + w11 * d;
+        }
+        if constexpr (!NHWC) {
+            if (live && c < C) dst[(((int64_t)n * C + c) * H + i) * W + j] = val;
+        } else if constexpr (sizeof(T) == 4) {
+            tile[lane * (WARP_CH + 1) + sub * CPT + k] = (float)val;
+        } else {
+            if (live && c < C) dst[pix * C + c] = val;
+        }
+    }
+    if constexpr (NHWC && sizeof(T) == 4) {
+        __syncthreads();
+        // 64 pixels x 64 channels -> rows of 64 consecutive channels per pixel
+        const int64_t pix0 = (int64_t)blockIdx.x * WARP_PIX;
+        const int ch = threadIdx.x & (WARP_CH - 1);
+#pragma unroll 4
+        for (int k = 0; k < WARP_PIX / WARP_SUB; ++k) {
+            const int p = k * WARP_SUB + sub;
+            if (pix0 + p < npix && cbase + ch < C)
+                dst[(pix0 + p) * C + cbase + ch] = (T)tile[p * (WARP_CH + 1) + ch];
+        }
+    }
+}
+
+template <typename T, bool NHWC>
+__global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_bwd(
+    const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
+    T *__restrict__ grad_src)
+{
+    const int lane = threadIdx.x & (WARP_PIX - 1);
+    const int sub = threadIdx.x / WARP_PIX;
+    const int64_t npix = (int64_t)N * H * W;
+    const int64_t pix = (int64_t)blockIdx.x * WARP_PIX + lane;
+    if (pix >= npix) return;
+    const int cbase = blockIdx.y * WARP_CH;
+    constexpr int CPT = WARP_CH / WARP_SUB;
+    const int n = (int)(pix / ((int64_t)H * W));
+    const int rem = (int)(pix - (int64_t)n * H * W);
+    const int i = rem / W, j = rem - i * W;
+    double x, y;
+    source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
+    const SrcCoord sc = make_coord(x, y, h, w);
+    if (!sc.any) return;
+    const T w00 = T(sc.wy0) * T(sc.wx0), w01 = T(sc.wy0) * T(sc.wx1);
+    const T w10 = T(sc.wy1) * T(sc.wx0), w11 = T(sc.wy1) * T(sc.wx1);
+    const int64_t plane = (int64_t)h * w;
+    const int64_t o00 = (int64_t)sc.y0 * w + sc.x0;
+    for (int k = 0; k < CPT; ++k) {
+        const int c = cbase + sub * CPT + k;
+        if (c >= C) break;
+        const T g = NHWC ? grad_dst[pix * C + c] : grad_dst[(((int64_t)n * C + c) * H + i) * W + j];
+        T *gp = grad_src + ((int64_t)n * C + c) * plane + o00;
+        if (sc.v00) atomicAdd(gp, w00 * g);
+        if (sc.v01) atomicAdd(gp + 1, w01 * g);
+        if (sc.v10) atomicAdd(gp + w, w10 * g);
+        if (sc.v11) atomicAdd(gp + w + 1, w11 * g);
+    }
+}
+
+template <typename T>
+static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int N, int C, int h, int w,
+                      int H, int W, int nhwc, T *o)
+{
+    if (N < 0 || C < 0 || h <= 0 || w <= 0 || H < 0 || W < 0) return (int)hipErrorInvalidValue;
+    const int64_t npix = (int64_t)N * H * W;
+    if (npix == 0 || C == 0) return 0;
+    if (!a || !Mv || !o) return (int)hipErrorInvalidValue;
+    const int64_t gx = (npix + WARP_PIX - 1) / WARP_PIX;
+    const int gy = (C + WARP_CH - 1) / WARP_CH;
+    if (gx > 0x7fffffffLL || gy > 65535) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)gx, (unsigned)gy), block(WARP_PIX * WARP_SUB);
+    if (!backward) {
+        if (nhwc) hipLaunchKernelGGL((warp_fwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
+        else hipLaunchKernelGGL((warp_fwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
+    } else {
+        if (nhwc) hipLaunchKernelGGL((warp_bwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
+        else hipLaunchKernelGGL((warp_bwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace mvdetr
+
+extern "C" {
+
+int mvdetr_warp_perspective_forward_f32(void *stream, const float *src, const float *M, int n,
+                                        int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                        int layout_nhwc, float *dst)
+{
+    return mvdetr::warp_entry<float>(false, stream, src, M, n, channels, src_h, src_w, dst_h, dst_w,
+                                     layout_nhwc, dst);
+}
+
+int mvdetr_warp_perspective_forward_f64(void *stream, const double *src, const double *M, int n,
+                                        int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                        int layout_nhwc, double *dst)
+{
+    return mvdetr::warp_entry<double>(false, stream, src, M, n, channels, src_h, src_w, dst_h, dst_w,
+                                      layout_nhwc, dst);
+}
+
+int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, const float *M, int n,
+                                         int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                         int layout_nhwc, float *grad_src)
+{
+    return mvdetr::warp_entry<float>(true, stream, grad_dst, M, n, channels, src_h, src_w, dst_h, dst_w,
+                                     layout_nhwc, grad_src);
+}
+
+int mvdetr_warp_perspective_backward_f64(void *stream, const double *grad_dst, const double *M,
+                                         int n, int channels, int src_h, int src_w, int dst_h,
+                                         int dst_w, int layout_nhwc, double *grad_src)
+{
+    return mvdetr::warp_entry<double>(true, stream, grad_dst, M, n, channels, src_h, src_w, dst_h, dst_w,
+                                      layout_nhwc, grad_src);
+}
+
+}  // extern "C"

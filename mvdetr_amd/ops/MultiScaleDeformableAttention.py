@@ -1,0 +1,104 @@
+"""Python face of the native extension, with the reference pybind module's name and signatures.
+
+Reference: multiview_detector/models/ops/src/vision.cpp:13-16 (module def),
+ms_deform_attn.h:20-61 (device dispatch), cuda/ms_deform_attn_cuda.cu:20-153 (argument checks,
+output allocation, im2col_step chunking).  The kernels are reached through the C ABI of
+include/mvdetr_ops.h (ctypes) on torch's current HIP stream.
+
+Differences from the reference, all deliberate:
+  * kernel launch failures raise RuntimeError instead of being printf'd (cuh:948-952);
+  * the batch is not chunked by im2col_step -- the kernels take the whole batch in one launch --
+    but the divisibility check (cu:52) is kept so the same misuse raises the same way;
+  * forward output is allocated with empty() (the kernel writes every element) instead of zeros().
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+
+def _check_inputs(named):
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+    for name, t in named:
+        if not t.is_cuda:
+            # ms_deform_attn.h:38,60
+            raise RuntimeError("Not implemented on the CPU" if name == "value"
+                               else f"{name} must be a CUDA tensor")
+
+
+def _dims(value, spatial_shapes, sampling_loc, im2col_step):
+    batch, spatial_size, num_heads, channels = value.shape
+    num_levels = spatial_shapes.shape[0]
+    num_query, num_point = sampling_loc.shape[1], sampling_loc.shape[4]
+    step = min(batch, int(im2col_step))
+    if batch > 0 and (step <= 0 or batch % step != 0):
+        raise RuntimeError(f"batch({batch}) must divide im2col_step({step})")
+    return batch, spatial_size, num_heads, channels, num_levels, num_query, num_point
+
+
+def _meta(t, device):
+    if t.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes / level_start_index must be int64 (torch.long)")
+    return t
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                           im2col_step):
+    """-> Tensor[batch, num_query, num_heads*channels]  (vision.cpp:14; ms_deform_attn_cuda.cu:20-80)"""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight)])
+    B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    sfx = _lib.suffix(value.dtype)
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("value, sampling_loc and attn_weight must have the same dtype")
+    _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = getattr(_lib.lib(), f"mvdetr_msda_forward_{sfx}")(
+            _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            B, S, M, D, L, Lq, P, out.data_ptr())
+    _lib.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                            grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]  (vision.cpp:15; cu:83-153)"""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
+    sfx = _lib.suffix(value.dtype)
+    if any(t.dtype != value.dtype for t in (sampling_loc, attn_weight, grad_output)):
+        raise RuntimeError("value, sampling_loc, attn_weight and grad_output must have the same dtype")
+    _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)
+    grad_value = torch.zeros_like(value)              # accumulated with atomics
+    grad_loc = torch.empty_like(sampling_loc)         # fully written
+    grad_aw = torch.empty_like(attn_weight)           # fully written
+    with torch.cuda.device(value.device):
+        rc = getattr(_lib.lib(), f"mvdetr_msda_backward_{sfx}")(
+            _lib.current_stream_ptr(value.device), grad_output.data_ptr(), value.data_ptr(),
+            spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), B, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(),
+            grad_aw.data_ptr())
+    _lib.check(rc, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_aw]
+
+
+def last_forward_impl() -> str:
+    """Which kernel variant the last forward on this thread dispatched to (bench/tests only)."""
+    return _lib.lib().mvdetr_msda_last_forward_impl().decode()
+
+
+_IMPLS = {"auto": 0, "gather": 1, "tile": 2}
+
+
+def set_forward_impl(name: str) -> str:
+    """Tuning/testing knob: 'auto' | 'gather' | 'tile'.  Returns the previous setting."""
+    prev = _lib.lib().mvdetr_msda_set_forward_impl(_IMPLS[name])
+    return {v: k for k, v in _IMPLS.items()}[prev]

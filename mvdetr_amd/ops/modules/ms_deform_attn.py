@@ -1,0 +1,101 @@
+"""MSDeformAttn module with the MVDeTr contract (5-D reference points).
+
+Mirrors multiview_detector/models/ops/modules/ms_deform_attn.py:30-117: same constructor,
+parameter names (sampling_offsets, attention_weights, value_proj, output_proj -- reference
+checkpoints load unchanged), initialisation, and forward arithmetic; the core runs on the HIP
+extension through MSDeformAttnFunction.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..functions import MSDeformAttnFunction
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError(f"invalid input for _is_power_of_2: {n} (type: {type(n)})")
+    return n != 0 and (n & (n - 1)) == 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        """d_model hidden size; n_levels feature levels (= cameras in MVDeTr); n_heads attention
+        heads; n_points sampling points per head per level."""
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: a power-of-two head dimension maps best onto the wave64 "
+                          "lane groups of the HIP kernels.")
+        self.im2col_step = 64          # kept for API parity; the HIP kernels do not chunk the batch
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._validated = None
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # ms_deform_attn.py:62-77: zero offset weights, bias = unit 8-neighbourhood directions
+        # scaled by (point index + 1); zero attention logits (uniform weights); xavier projections
+        nn.init.constant_(self.sampling_offsets.weight.data, 0.0)
+        ang = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        dirs = torch.stack([ang.cos(), ang.sin()], -1)
+        dirs = dirs / dirs.abs().max(-1, keepdim=True)[0]
+        grid = dirs.view(self.n_heads, 1, 1, 2).repeat(1, self.n_levels, self.n_points, 1)
+        grid = grid * torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.reshape(-1))
+        nn.init.constant_(self.attention_weights.weight.data, 0.0)
+        nn.init.constant_(self.attention_weights.bias.data, 0.0)
+        nn.init.xavier_uniform_(self.value_proj.weight.data)
+        nn.init.constant_(self.value_proj.bias.data, 0.0)
+        nn.init.xavier_uniform_(self.output_proj.weight.data)
+        nn.init.constant_(self.output_proj.bias.data, 0.0)
+
+    def _check_lengths(self, spatial_shapes, len_in):
+        # the reference asserts sum(H*W) == Len_in on every call (ms_deform_attn.py:94), which is a
+        # device->host sync per layer; validate each (tensor, length) pair once instead
+        key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(spatial_shapes.shape), len_in)
+        if self._validated != key:
+            assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == len_in
+            self._validated = key
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        """query (N, Lq, C); reference_points (N, Lq, n_levels, n_points, 2) in [0,1] -- MVDeTr's 5-D
+        form (ms_deform_attn.py:104-107) -- or (..., 4) boxes; input_flatten (N, sum H_l*W_l, C);
+        input_spatial_shapes (n_levels, 2); input_level_start_index (n_levels,);
+        input_padding_mask (N, sum H_l*W_l) True = padding.  Returns (N, Lq, C)."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        self._check_lengths(input_spatial_shapes, Len_in)
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+        if reference_points.shape[-1] == 2:
+            normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            locations = reference_points[:, :, None, :, :, :] \
+                + offsets / normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            locations = reference_points[:, :, None, :, None, :2] \
+                + offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
+                             .format(reference_points.shape[-1]))
+        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                         locations.contiguous(), weights, self.im2col_step)
+        return self.output_proj(out)

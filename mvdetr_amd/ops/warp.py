@@ -1,0 +1,66 @@
+"""warp_perspective: the feature -> ground-plane homography warp of MVDeTr as one HIP kernel.
+
+Drop-in for the reference's ``kornia.warp_perspective(src, M, dsize, mode='bilinear',
+padding_mode='zeros', align_corners=False)`` call (multiview_detector/models/mvdetr.py:194-195;
+also frameDataset.py:80, grid_visualize.py:19-21).  Differentiable w.r.t. ``src``.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib
+
+
+def _launch(name, a, M, n, c, h, w, H, W, nhwc, out):
+    with torch.cuda.device(a.device):
+        rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_{name}_{_lib.suffix(a.dtype)}")(
+            _lib.current_stream_ptr(a.device), a.data_ptr(), M.data_ptr(), n, c, h, w, H, W,
+            1 if nhwc else 0, out.data_ptr())
+    _lib.check(rc, f"warp_perspective_{name}")
+
+
+class WarpPerspectiveFunction(Function):
+    @staticmethod
+    def forward(ctx, src, M, dsize, channels_last_out):
+        n, c, h, w = src.shape
+        H, W = int(dsize[0]), int(dsize[1])
+        shape = (n, H, W, c) if channels_last_out else (n, c, H, W)
+        out = torch.empty(shape, dtype=src.dtype, device=src.device)
+        _launch("forward", src, M, n, c, h, w, H, W, channels_last_out, out)
+        ctx.save_for_backward(M)
+        ctx.geom = (n, c, h, w, H, W, channels_last_out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (M,) = ctx.saved_tensors
+        n, c, h, w, H, W, nhwc = ctx.geom
+        grad_src = torch.zeros((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device)
+        _launch("backward", grad_out.contiguous(), M, n, c, h, w, H, W, nhwc, grad_src)
+        return grad_src, None, None, None
+
+
+def warp_perspective(src, M, dsize, mode="bilinear", padding_mode="zeros", align_corners=False,
+                     channels_last_out=False):
+    """src [N,C,h,w] -> [N,C,H,W] (or [N,H,W,C] with ``channels_last_out``), sampling the source at
+    the pre-image of every destination pixel under ``M [N,3,3]`` (destination pixel <- source
+    pixel), with kornia's normalisation convention.
+
+    ``M`` may live on the CPU (mvdetr.py:194 moves it each call); it is copied to ``src``'s device.
+    Only the configuration MVDeTr's model uses is implemented natively: bilinear, zero padding,
+    align_corners=False.
+    """
+    if mode != "bilinear" or padding_mode != "zeros" or align_corners not in (False, None):
+        raise NotImplementedError(
+            "warp_perspective: only mode='bilinear', padding_mode='zeros', align_corners=False "
+            "(the MVDeTr model configuration) is implemented")
+    if src.dim() != 4 or M.shape[-2:] != (3, 3) or M.reshape(-1, 3, 3).shape[0] != src.shape[0]:
+        raise ValueError(f"warp_perspective: expected src [N,C,h,w] and M [N,3,3], got "
+                         f"{tuple(src.shape)} and {tuple(M.shape)}")
+    if not src.is_cuda:
+        raise RuntimeError("warp_perspective: not implemented on the CPU (HIP extension only)")
+    M = M.reshape(-1, 3, 3).to(device=src.device, dtype=src.dtype).contiguous()
+    return WarpPerspectiveFunction.apply(src.contiguous(), M, tuple(dsize), bool(channels_last_out))

@@ -1,0 +1,288 @@
+"""GPU parity tests of multi-scale deformable attention: HIP kernels (through the product API and
+the C ABI) against the oracle, the golden vectors produced by the reference, and size-independent
+properties at the full Wildtrack shape.  Tolerance for fp32: 1e-4 absolute on O(1) features
+(BASELINE.json north_star); fp64: torch.allclose defaults like ops/test.py:40."""
+import pytest
+import torch
+
+from conftest import load_golden, t
+from helpers import encoder_msda_inputs, level_start_index, random_msda_inputs
+from oracle import c_oracle, torch_oracle
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mvdetr_amd.ops  # noqa: F401
+    from mvdetr_amd.ops.functions import MSDeformAttnFunction
+    import MultiScaleDeformableAttention as MSDA
+    return MSDeformAttnFunction, MSDA
+
+
+def dev(*xs):
+    return [x.cuda() for x in xs]
+
+
+def run_fwd(ops, value, shapes, lsi, loc, aw, step=64):
+    F, _ = ops
+    return F.apply(*dev(value, shapes, lsi, loc, aw), step).cpu()
+
+
+# ---- golden vectors ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_forward_testpy_golden(ops, tag):
+    g = load_golden(f"msda_testpy_{tag}.npz")
+    out = run_fwd(ops, t(g["value"]), t(g["shapes"]), t(g["level_start_index"]), t(g["loc"]), t(g["aw"]), 2)
+    ref = t(g["out"])
+    if tag == "f64":
+        assert torch.allclose(out, ref)
+        assert (out - ref).abs().max().item() < 1e-15
+    else:
+        assert torch.allclose(out, ref, rtol=1e-2, atol=1e-3)       # the reference's own bar (test.py:56)
+        assert (out - ref).abs().max().item() < 1e-8                 # ours (values are ~0.01)
+
+
+def test_forward_mini_golden(ops):
+    g = load_golden("msda_mini.npz")
+    args = [t(g[k]) for k in ("value", "shapes", "level_start_index", "loc", "aw")]
+    out32 = run_fwd(ops, *args)
+    assert (out32 - t(g["out_f32"])).abs().max().item() < FP32_TOL
+    assert (out32.double() - t(g["out"])).abs().max().item() < FP32_TOL
+    out64 = run_fwd(ops, args[0].double(), args[1], args[2], args[3].double(), args[4].double())
+    assert (out64 - t(g["out"])).abs().max().item() < 1e-12
+
+
+def test_forward_edges_golden(ops):
+    g = load_golden("msda_edges.npz")
+    args = [t(g[k]) for k in ("value", "shapes", "level_start_index", "loc", "aw")]
+    assert (run_fwd(ops, *args) - t(g["out"])).abs().max().item() < 1e-12
+    out32 = run_fwd(ops, args[0].float(), args[1], args[2], args[3].float(), args[4].float())
+    assert (out32.double() - t(g["out"])).abs().max().item() < FP32_TOL
+
+
+def test_backward_mini_golden(ops):
+    _, MSDA = ops
+    g = load_golden("msda_mini.npz")
+    v, s, lsi, loc, aw, go = [t(g[k]) for k in ("value", "shapes", "level_start_index", "loc", "aw", "grad_out")]
+    gv, gl, ga = [x.cpu() for x in MSDA.ms_deform_attn_backward(
+        *dev(v.double(), s, lsi, loc.double(), aw.double(), go.double()), 64)]
+    assert (gv - t(g["grad_value"])).abs().max().item() < 1e-11
+    assert (gl - t(g["grad_loc"])).abs().max().item() < 1e-10
+    assert (ga - t(g["grad_aw"])).abs().max().item() < 1e-11
+    gv, gl, ga = [x.cpu().double() for x in MSDA.ms_deform_attn_backward(*dev(v, s, lsi, loc, aw, go), 64)]
+    assert (gv - t(g["grad_value"])).abs().max().item() < 1e-4
+    assert (ga - t(g["grad_aw"])).abs().max().item() < 1e-4
+    # grad_loc carries a factor W (or H) and a D-term sum: relative bar
+    ref = t(g["grad_loc"])
+    assert ((gl - ref).abs() / (1 + ref.abs())).max().item() < 1e-4
+
+
+# ---- random shapes against the oracle -----------------------------------------------------------------
+SHAPES = [
+    # B, levels, M, D, Lq, P
+    (1, [(6, 4), (3, 2)], 2, 2, 2, 2),                       # ops/test.py
+    (2, [(8, 8), (4, 4), (2, 2), (1, 1)], 8, 32, 37, 4),     # Deformable-DETR-like pyramid
+    (1, [(5, 7)] * 3, 4, 16, 105, 4),                        # small MVDeTr-like (Lq == S)
+    (3, [(9, 11), (3, 5)], 1, 1, 13, 1),                     # scalar channels, single head/point
+    (2, [(7, 3)], 3, 30, 5, 3),                              # D not a multiple of 4
+    (1, [(4, 4), (6, 2)], 2, 71, 9, 2),                      # odd D
+    (1, [(3, 3)], 1, 1025, 3, 1),                            # D > 1024 (reference's multi-block path)
+    (1, [(5, 9)] * 6, 8, 16, 270, 4),                        # MultiviewX-like
+    (1, [(4, 6)] * 16, 8, 32, 384, 4),                       # 16 cameras, 256 channels
+]
+
+
+@pytest.mark.parametrize("B,lv,M,D,Lq,P", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_forward_vs_oracle(ops, B, lv, M, D, Lq, P, dtype):
+    value, shapes, lsi, loc, aw = random_msda_inputs(B, lv, M, D, Lq, P, seed=B + D + Lq, dtype=dtype)
+    out = run_fwd(ops, value, shapes, lsi, loc, aw, step=B)
+    ref64 = c_oracle.msda_forward(value.double(), shapes, lsi, loc.double(), aw.double())
+    tol = FP32_TOL if dtype == torch.float32 else 1e-12
+    assert out.shape == (B, Lq, M * D)
+    assert (out.double() - ref64).abs().max().item() < tol
+    if dtype == torch.float32:          # and against the fp32 torch formulation the reference falls back to
+        assert (out - torch_oracle.msda_core(value, shapes, loc, aw)).abs().max().item() < FP32_TOL
+
+
+@pytest.mark.parametrize("B,lv,M,D,Lq,P", SHAPES)
+def test_backward_vs_oracle(ops, B, lv, M, D, Lq, P):
+    _, MSDA = ops
+    value, shapes, lsi, loc, aw = random_msda_inputs(B, lv, M, D, Lq, P, seed=7 + D, dtype=torch.float64)
+    go = torch.randn(B, Lq, M * D, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    ref = c_oracle.msda_backward(value, shapes, lsi, loc, aw, go)
+    got = [x.cpu() for x in MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), B)]
+    for a, b, name in zip(got, ref, ("grad_value", "grad_loc", "grad_aw")):
+        assert a.shape == b.shape
+        assert ((a - b).abs() / (1 + b.abs())).max().item() < 1e-10, name
+    got32 = [x.cpu().double() for x in MSDA.ms_deform_attn_backward(
+        *dev(value.float(), shapes, lsi, loc.float(), aw.float(), go.float()), B)]
+    for a, b, name in zip(got32, ref, ("grad_value", "grad_loc", "grad_aw")):
+        assert ((a - b).abs() / (1 + b.abs())).max().item() < 2e-4 * max(1.0, D / 64), name
+
+
+@pytest.mark.parametrize("channels", [30, 32, 64, 71, 1025, 2048, 3096])
+def test_gradcheck_channel_sweep(ops, channels):
+    """ops/test.py:63-86: gradcheck in fp64 over the D values that select every backward variant."""
+    F, _ = ops
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    value = (torch.rand(N, S, M, channels) * 0.01).double().cuda().requires_grad_(True)
+    loc = torch.rand(N, Lq, M, L, P, 2).double().cuda().requires_grad_(True)
+    aw = torch.rand(N, Lq, M, L, P) + 1e-5
+    aw = (aw / aw.sum((-1, -2), keepdim=True)).double().cuda().requires_grad_(True)
+    assert torch.autograd.gradcheck(F.apply, (value, shapes.cuda(), level_start_index(shapes).cuda(), loc, aw, 2))
+
+
+def test_autograd_through_function_matches_oracle_autograd(ops):
+    F, _ = ops
+    value, shapes, lsi, loc, aw = random_msda_inputs(2, [(6, 5), (3, 4)], 4, 16, 21, 4, seed=5, dtype=torch.float64)
+    leaves = [x.clone().requires_grad_(True) for x in (value, loc, aw)]
+    out_ref = torch_oracle.msda_core(leaves[0], shapes, leaves[1], leaves[2])
+    go = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    ref = torch.autograd.grad(out_ref, leaves, go)
+    dl = [x.clone().cuda().requires_grad_(True) for x in (value, loc, aw)]
+    out = F.apply(dl[0], shapes.cuda(), lsi.cuda(), dl[1], dl[2], 64)
+    got = torch.autograd.grad(out, dl, go.cuda())
+    for a, b in zip(got, ref):
+        assert (a.cpu() - b).abs().max().item() < 1e-10
+
+
+# ---- ragged / empty / misuse ----------------------------------------------------------------------------
+def test_empty_queries_and_batch(ops):
+    F, MSDA = ops
+    value, shapes, lsi, loc, aw = random_msda_inputs(2, [(4, 4)], 2, 8, 0, 2)
+    out = run_fwd(ops, value, shapes, lsi, loc, aw)
+    assert out.shape == (2, 0, 16)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, out), 64)
+    assert gv.shape == value.shape and float(gv.abs().sum()) == 0.0 and gl.numel() == 0 and ga.numel() == 0
+
+
+def test_all_taps_outside_give_zero(ops):
+    value, shapes, lsi, loc, aw = random_msda_inputs(1, [(4, 5), (2, 3)], 2, 16, 11, 4, lo=1.5, hi=3.0)
+    assert float(run_fwd(ops, value, shapes, lsi, loc, aw).abs().max()) == 0.0
+    value, shapes, lsi, loc, aw = random_msda_inputs(1, [(4, 5), (2, 3)], 2, 16, 11, 4, lo=-3.0, hi=-0.6)
+    assert float(run_fwd(ops, value, shapes, lsi, loc, aw).abs().max()) == 0.0
+
+
+def test_nan_locations_do_not_fault(ops):
+    value, shapes, lsi, loc, aw = random_msda_inputs(1, [(4, 5)], 2, 16, 8, 2)
+    loc[0, 3] = float("nan")
+    out = run_fwd(ops, value, shapes, lsi, loc, aw)
+    ref = torch_oracle.msda_core(value, shapes, loc, aw)
+    keep = [i for i in range(8) if i != 3]
+    assert (out[0, keep] - ref[0, keep]).abs().max().item() < FP32_TOL
+    assert float(out[0, 3].abs().max()) == 0.0          # the > -1 / < size guard rejects NaN (cuh:288)
+
+
+def test_misuse_raises_like_reference(ops):
+    F, MSDA = ops
+    value, shapes, lsi, loc, aw = dev(*random_msda_inputs(3, [(4, 4)], 2, 8, 5, 2))
+    with pytest.raises(RuntimeError, match="must divide im2col_step"):
+        MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 2)
+    with pytest.raises(RuntimeError, match="sampling_loc tensor has to be contiguous"):
+        MSDA.ms_deform_attn_forward(value, shapes, lsi, loc.transpose(1, 2).contiguous().transpose(1, 2), aw, 3)
+    with pytest.raises(RuntimeError, match="spatial_shapes must be a CUDA tensor"):
+        MSDA.ms_deform_attn_forward(value, shapes.cpu(), lsi, loc, aw, 3)
+    with pytest.raises(RuntimeError, match="not implemented for"):
+        MSDA.ms_deform_attn_forward(value.half(), shapes, lsi, loc.half(), aw.half(), 3)
+
+
+def test_inputs_are_not_mutated_and_stream_is_respected(ops):
+    F, _ = ops
+    args = dev(*random_msda_inputs(1, [(6, 6)] * 2, 4, 16, 72, 4, seed=3))
+    before = [a.clone() for a in args]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out_side = F.apply(*args, 64)
+    side.synchronize()
+    out_main = F.apply(*args, 64)
+    torch.cuda.synchronize()
+    assert torch.equal(out_side, out_main)
+    for a, b in zip(args, before):
+        assert torch.equal(a, b)
+
+
+# ---- module level ------------------------------------------------------------------------------------------
+def test_module_golden(ops):
+    from mvdetr_amd.ops.modules import MSDeformAttn
+    g = load_golden("msda_module.npz")
+    d_model, L, M, P = (int(x) for x in g["dims"])
+    mod = MSDeformAttn(d_model, L, M, P)
+    mod.load_state_dict({k[2:]: t(v) for k, v in g.items() if k.startswith("p.")})
+    mod = mod.cuda()
+    shapes = t(g["shapes"]).cuda()
+    out = mod(t(g["query"]).cuda(), t(g["ref"]).cuda(), t(g["src"]).cuda(), shapes, level_start_index(shapes))
+    assert (out.cpu() - t(g["out"])).abs().max().item() < FP32_TOL
+    # 4-D reference points are not part of MVDeTr's contract (ms_deform_attn.py:106 indexes 5-D)
+    with pytest.raises(IndexError):
+        mod(t(g["query"]).cuda(), t(g["ref"]).cuda()[:, :, :, 0], t(g["src"]).cuda(), shapes, level_start_index(shapes))
+
+
+# ---- full Wildtrack shape ------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def wildtrack_inputs():
+    return encoder_msda_inputs(7, 60, 180, seed=0)
+
+
+def test_wildtrack_forward_vs_oracle(ops, wildtrack_inputs):
+    value, shapes, lsi, loc, aw = wildtrack_inputs
+    out = run_fwd(ops, value, shapes, lsi, loc, aw)
+    ref = c_oracle.msda_forward(value, shapes, lsi, loc, aw)          # fp32 C oracle, all 75,600 queries
+    assert (out - ref).abs().max().item() < FP32_TOL
+    sub = slice(0, 75600, 97)                                         # fp64 truth on a strided subset
+    ref64 = c_oracle.msda_forward(value.double(), shapes, lsi, loc[:, sub].double().contiguous(),
+                                  aw[:, sub].double().contiguous())
+    assert (out[:, sub].double() - ref64).abs().max().item() < FP32_TOL
+
+
+def test_wildtrack_adversarial_uniform_locations(ops):
+    value, shapes, lsi, loc, aw = random_msda_inputs(1, [(60, 180)] * 7, 8, 16, 75600, 4, seed=1, lo=0.0, hi=1.0)
+    out = run_fwd(ops, value, shapes, lsi, loc, aw)
+    ref = c_oracle.msda_forward(value, shapes, lsi, loc, aw)
+    assert (out - ref).abs().max().item() < FP32_TOL
+
+
+def test_wildtrack_linearity_and_weight_scaling(ops, wildtrack_inputs):
+    """Size-independent properties: the op is linear in value and in the attention weights."""
+    value, shapes, lsi, loc, aw = dev(*wildtrack_inputs)
+    F, _ = ops
+    v2 = torch.randn_like(value)
+    a = F.apply(value, shapes, lsi, loc, aw, 64)
+    b = F.apply(v2, shapes, lsi, loc, aw, 64)
+    ab = F.apply(2 * value - 3 * v2, shapes, lsi, loc, 0.5 * aw, 64)
+    assert (ab - 0.5 * (2 * a - 3 * b)).abs().max().item() < 2e-5
+    # constant value field + weights that sum to 1 and taps well inside => output == the constant
+    ones = torch.ones_like(value)
+    inside = (loc * 0.5 + 0.25).contiguous()
+    out = F.apply(ones, shapes, lsi, inside, aw, 64)
+    assert (out - 1).abs().max().item() < 1e-5
+
+
+def test_wildtrack_backward_checksums(ops, wildtrack_inputs):
+    """sum(grad_value) == sum over taps of aw * in-bounds bilinear mass * grad_out, checked through
+    the identity <grad_out, f(value)> == <grad_value, value> (adjoint test), at full size."""
+    _, MSDA = ops
+    F, _ = ops
+    value, shapes, lsi, loc, aw = dev(*wildtrack_inputs)
+    go = torch.randn(1, 75600, 128, device="cuda")
+    gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, go, 64)
+    out = F.apply(value, shapes, lsi, loc, aw, 64)
+    lhs = (go.double() * out.double()).sum().item()
+    rhs = (gv.double() * value.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * (abs(lhs) + 1e3)
+    # <grad_aw, aw> == <grad_out, out> as well (out is linear in aw)
+    rhs2 = (ga.double() * aw.double()).sum().item()
+    assert abs(lhs - rhs2) < 1e-6 * (abs(lhs) + 1e3)
+    # and a strided subset of grad_loc / grad_aw against the fp64 oracle
+    sub = slice(0, 75600, 997)
+    lo, awc, goc = [x[:, sub].cpu().double().contiguous() for x in (loc, aw, go)]
+    _, rl, ra = c_oracle.msda_backward(value.cpu().double(), shapes.cpu(), lsi.cpu(), lo, awc, goc)
+    assert ((gl[:, sub].cpu().double() - rl).abs() / (1 + rl.abs())).max().item() < 1e-4
+    assert ((ga[:, sub].cpu().double() - ra).abs() / (1 + ra.abs())).max().item() < 1e-4

@@ -1,0 +1,127 @@
+"""GPU parity tests of the homography warp kernel against the oracle's restatement of
+kornia.warp_perspective (see oracle/torch_oracle.py for the parity status of that restatement)."""
+import pytest
+import torch
+
+from conftest import load_golden, t
+from helpers import smooth_features
+from mvdetr_amd import geometry
+from oracle import c_oracle, torch_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def warp():
+    from mvdetr_amd.ops import warp_perspective
+    return warp_perspective
+
+
+def wildtrack_mats(aug_seed=None, geom=geometry.WILDTRACK):
+    Ks, Rts = geometry.synthetic_rig(geom, seed=0)
+    pm = geometry.build_proj_mats(geom, Ks, Rts)
+    M = torch.eye(3).repeat(1, geom.num_cam, 1, 1) if aug_seed is None else \
+        geometry.random_affine_mats(1, geom.num_cam, geom.input_img_shape, seed=aug_seed)
+    return geometry.compose_frame_proj_mats(pm, M, geom.img_reduce)
+
+
+def test_golden_fixture(warp):
+    g = load_golden("warp_restatement.npz")
+    src, M = t(g["src"]), t(g["M"])
+    out64 = warp(src.cuda(), M, (12, 36)).cpu()
+    assert (out64 - t(g["out"])).abs().max().item() < 1e-11
+    out32 = warp(src.float().cuda(), M.float(), (12, 36)).cpu()
+    assert (out32.double() - t(g["out"])).abs().max().item() < 1e-4
+    assert (out32 - t(g["out_f32"])).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("aug", [None, 1])
+def test_wildtrack_white_noise_vs_fp64_oracle(warp, aug):
+    """White-noise features are the adversarial case: O(1) change per source pixel.  The kernel
+    evaluates the geometry in fp64, so it sits on the fp64 oracle; the fp32 torch op chain (what the
+    reference runs) is itself ~2e-4 off near the horizon, which bounds the agreement with it."""
+    M = wildtrack_mats(aug)
+    src = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(0))
+    out = warp(src.cuda(), M, (120, 360)).cpu()
+    ref64 = c_oracle.warp_perspective(src.double(), M.double(), (120, 360))
+    assert (out.double() - ref64).abs().max().item() < 1e-5
+    ref32 = torch_oracle.warp_perspective(src, M, (120, 360))
+    oracle_own = (ref32.double() - ref64).abs()
+    diff = (out - ref32).abs().double()
+    assert (diff <= 1e-4 + 1.5 * oracle_own).all()
+    assert (diff < 1e-4).double().mean().item() > 0.9999
+    frac_zero = (out == 0).float().mean().item()
+    assert 0.1 < frac_zero < 0.6           # a good part of the plane is outside each camera's view
+
+
+@pytest.mark.parametrize("aug", [None, 2])
+def test_wildtrack_smooth_features_within_1e4_of_fp32_reference_path(warp, aug):
+    M = wildtrack_mats(aug)
+    src = smooth_features(7, 128, 90, 160, seed=3)
+    out = warp(src.cuda(), M, (120, 360)).cpu()
+    ref32 = torch_oracle.warp_perspective(src, M, (120, 360))
+    assert (out - ref32).abs().max().item() < 1e-4
+
+
+def test_channels_last_output_equals_permuted(warp):
+    M = wildtrack_mats(3)
+    src = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(1)).cuda()
+    a = warp(src, M, (120, 360))
+    b = warp(src, M, (120, 360), channels_last_out=True)
+    assert b.shape == (7, 120, 360, 128)
+    assert torch.equal(a.permute(0, 2, 3, 1), b)
+    # ragged channel / pixel counts (not multiples of 64)
+    src = torch.randn(3, 37, 11, 13, generator=torch.Generator().manual_seed(2)).cuda()
+    Ms = wildtrack_mats(None)[:3] @ torch.diag(torch.tensor([12.0, 12.0, 1.0]))
+    Ms = torch.diag(torch.tensor([0.1, 0.1, 1.0])) @ Ms
+    a = warp(src, Ms, (9, 21))
+    b = warp(src, Ms, (9, 21), channels_last_out=True)
+    assert torch.equal(a.permute(0, 2, 3, 1), b)
+    ref = c_oracle.warp_perspective(src.cpu().double(), Ms.double(), (9, 21))
+    assert (a.cpu().double() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_backward_vs_oracle(warp, nhwc):
+    g = load_golden("warp_restatement.npz")
+    src, M = t(g["src"]).cuda().requires_grad_(True), t(g["M"])
+    out = warp(src, M, (12, 36), channels_last_out=nhwc)
+    go = torch.randn(2, 8, 12, 36, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    (gs,) = torch.autograd.grad(out, src, (go.permute(0, 2, 3, 1) if nhwc else go).contiguous().cuda())
+    ref = c_oracle.warp_perspective_backward(go, M, (9, 16))
+    assert (gs.cpu() - ref).abs().max().item() < 1e-10
+
+
+def test_gradcheck_small(warp):
+    g = load_golden("warp_restatement.npz")
+    src = t(g["src"])[:, :3].contiguous().cuda().requires_grad_(True)
+    M = t(g["M"])
+    assert torch.autograd.gradcheck(lambda s: warp(s, M, (6, 10)), (src,))
+
+
+def test_degenerate_and_misuse(warp):
+    src = torch.randn(1, 4, 5, 6).cuda()
+    # a homography that maps everything far outside: all zeros, no fault
+    far = torch.tensor([[[1.0, 0, 1e6], [0, 1, 1e6], [0, 0, 1]]])
+    assert float(warp(src, far, (7, 9)).abs().max()) == 0.0
+    # singular matrix: kornia would produce inf/nan grids -> zeros after the bounds test; must not fault
+    sing = torch.zeros(1, 3, 3)
+    out = warp(src, sing, (7, 9))
+    assert out.shape == (1, 4, 7, 9) and torch.isfinite(out).all()
+    # empty
+    assert warp(src[:0], far[:0], (7, 9)).shape == (0, 4, 7, 9)
+    with pytest.raises(NotImplementedError):
+        warp(src, far, (7, 9), "nearest")
+    with pytest.raises(ValueError):
+        warp(src, far.repeat(2, 1, 1), (7, 9))
+
+
+def test_identity_homography_shows_kornia_normalisation_quirk(warp):
+    """With M = I and equal sizes the result is NOT the identity: kornia normalises with the
+    corner-aligned map but samples with align_corners=False (x = j*w/(w-1) - 0.5)."""
+    src = torch.arange(8.0).view(1, 1, 1, 8).repeat(1, 1, 3, 1).cuda()
+    out = warp(src, torch.eye(3)[None], (3, 8))[0, 0, 1].cpu()
+    expect = torch.tensor([j * 8 / 7 - 0.5 for j in range(8)])
+    expect[0] = 0.5 * 0.0 + 0.5 * 0.0      # x = -0.5: half of pixel 0 (value 0) and half padding
+    expect[7] = 0.5 * 7.0                  # x = 7.5: half of pixel 7, half padding
+    assert (out - expect).abs().max().item() < 1e-5

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Kernel-level timings of the hot path on one GPU (HIP events on torch's current stream).
+
+    python tools/microbench.py [--config wildtrack|multiviewx|stress16] [--iters 50]
+
+Prints one line per kernel: average us, algorithmic GB/s (SURVEY 8d byte counts), fraction of the
+8 TB/s HBM peak.  Used while tuning; bench.py is the contract-level benchmark.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+
+from helpers import encoder_msda_inputs, random_msda_inputs  # noqa: E402
+from mvdetr_amd import geometry  # noqa: E402
+import mvdetr_amd.ops  # noqa: E402,F401
+from mvdetr_amd.ops import warp_perspective  # noqa: E402
+import MultiScaleDeformableAttention as MSDA  # noqa: E402
+
+PEAK = 8.0e12
+
+
+def time_us(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(iters))
+    return sum(ts) / len(ts), ts[len(ts) // 2], ts[0]
+
+
+def report(name, us, nbytes):
+    avg, med, mn = us
+    print(f"{name:34s} avg {avg:9.1f} us  med {med:9.1f}  min {mn:9.1f}   {nbytes / avg / 1e3:8.1f} GB/s (alg)  "
+          f"{nbytes / avg * 1e6 / PEAK * 100:5.1f}% of 8 TB/s", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="wildtrack")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--skip-bwd", action="store_true")
+    a = ap.parse_args()
+    geom = geometry.GEOMETRIES[a.config]
+    L = geom.num_cam
+    H, W = geom.Rworld_shape[0] // 2, geom.Rworld_shape[1] // 2
+    C = geom.feat_channels
+    M, D, P, B = 8, C // 8, 4, a.batch
+    S = L * H * W
+    print(f"# {a.config}: L={L} token map {H}x{W} S=Lq={S} M={M} D={D} P={P} B={B}  device={torch.cuda.get_device_name(0)}")
+    fwd_bytes = 4 * B * (S * M * D + 3 * S * M * L * P + S * M * D)
+    bwd_bytes = 4 * B * (S * M * D + 2 * S * M * D + 6 * S * M * L * P)
+
+    for tag, maker in (("realistic", lambda: encoder_msda_inputs(L, H, W, M, D, P, B=B, seed=0)),
+                       ("uniform", lambda: random_msda_inputs(B, [(H, W)] * L, M, D, S, P, seed=1, lo=0, hi=1))):
+        value, shapes, lsi, loc, aw = [x.cuda() for x in maker()]
+        for impl in ("gather", "tile"):
+            MSDA.set_forward_impl(impl)
+            fn = lambda: MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)  # noqa: E731
+            fn()
+            used = MSDA.last_forward_impl()
+            if used == impl:
+                report(f"msda_fwd[{tag}] impl={used}", time_us(fn, a.iters), fwd_bytes)
+        MSDA.set_forward_impl("auto")
+        if not a.skip_bwd:
+            go = torch.randn(B, S, M * D, device="cuda")
+            fn = lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, go, 64)  # noqa: E731
+            report(f"msda_bwd[{tag}] (+memset)", time_us(fn, max(5, a.iters // 5)), bwd_bytes)
+
+    h, w = geom.Rimg_shape
+    Hw, Ww = geom.Rworld_shape
+    Ks, Rts = geometry.synthetic_rig(geom, seed=0)
+    pm = geometry.build_proj_mats(geom, Ks, Rts)
+    Mx = geometry.compose_frame_proj_mats(pm, torch.eye(3).repeat(1, L, 1, 1), geom.img_reduce).cuda()
+    src = torch.randn(L, C, h, w, device="cuda")
+    wbytes = 4 * L * C * (h * w + Hw * Ww)
+    report("warp_fwd NCHW", time_us(lambda: warp_perspective(src, Mx, (Hw, Ww)), a.iters), wbytes)
+    report("warp_fwd NHWC", time_us(lambda: warp_perspective(src, Mx, (Hw, Ww), channels_last_out=True), a.iters), wbytes)
+    # for scale: a plain device copy of the same number of bytes
+    x = torch.empty(wbytes // 8, device="cuda")
+    y = torch.empty_like(x)
+    report("torch copy (same bytes as warp)", time_us(lambda: y.copy_(x), a.iters), wbytes)
+
+
+if __name__ == "__main__":
+    main()
