@@ -55,3 +55,24 @@ def smooth_features(n, c, h, w, seed=0, dtype=torch.float32):
         ph = torch.rand(n, c, 1, 1, generator=g) * 2 * math.pi
         out += torch.randn(n, c, 1, 1, generator=g) * torch.sin(2 * math.pi * (fy * ys + fx * xs) + ph)
     return out.to(dtype)
+
+
+def pyramid_encoder_inputs(shapes_hw, M=8, D=32, P=4, B=1, seed=0, noise_px=1.5, dtype=torch.float32):
+    """Deformable-DETR-style encoder inputs over levels of DIFFERENT sizes: Lq = S, each query's
+    reference point is its own normalised cell centre in every level, offsets ~ N(0, noise_px) pixels
+    of the sampled level."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = torch.as_tensor(shapes_hw, dtype=torch.long)
+    L = shapes.shape[0]
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(B, S, M, D, generator=g).to(dtype)
+    refs = []
+    for H, W in shapes_hw:
+        ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+        refs.append(torch.stack([xs / W, ys / H], -1).reshape(-1, 2))
+    ref = torch.cat(refs, 0)                                                     # [S,2]
+    wh = torch.tensor([[w, h] for h, w in shapes_hw], dtype=torch.float32)       # [L,2]
+    off = noise_px * torch.randn(B, S, M, L, P, 2, generator=g) / wh[None, None, None, :, None, :]
+    loc = ref[None, :, None, None, None, :] + off
+    aw = torch.softmax(torch.randn(B, S, M, L * P, generator=g), -1).view(B, S, M, L, P)
+    return value, shapes, level_start_index(shapes), loc.to(dtype).contiguous(), aw.to(dtype)

@@ -284,5 +284,95 @@ def test_wildtrack_backward_checksums(ops, wildtrack_inputs):
     sub = slice(0, 75600, 997)
     lo, awc, goc = [x[:, sub].cpu().double().contiguous() for x in (loc, aw, go)]
     _, rl, ra = c_oracle.msda_backward(value.cpu().double(), shapes.cpu(), lsi.cpu(), lo, awc, goc)
-    assert ((gl[:, sub].cpu().double() - rl).abs() / (1 + rl.abs())).max().item() < 1e-4
+    # grad_loc = W * a * sum_c g_c * dv_c: |terms| sum to ~1e2 at W = 180, so fp32 rounding is ~1e-5..1e-4
+    assert (gl[:, sub].cpu().double() - rl).abs().max().item() < 1e-3
+    assert ((gl[:, sub].cpu().double() - rl).abs() / (10 + rl.abs())).max().item() < 1e-5
     assert ((ga[:, sub].cpu().double() - ra).abs() / (1 + ra.abs())).max().item() < 1e-4
+
+
+# ---- the LDS-tiled encoder kernel vs the gather kernel vs the oracle ------------------------------------------
+@pytest.fixture
+def msda_impl(ops):
+    _, MSDA = ops
+    yield MSDA
+    MSDA.set_forward_impl("auto")
+
+
+def _fwd_impl(MSDA, impl, args):
+    MSDA.set_forward_impl(impl)
+    out = MSDA.ms_deform_attn_forward(*dev(*args), 64).cpu()
+    return out, MSDA.last_forward_impl()
+
+
+TILE_CASES = {
+    "mvdetr_like_partial_tiles": lambda: encoder_msda_inputs(7, 21, 43, seed=2, noise_px=1.0),
+    "multiviewx_like": lambda: encoder_msda_inputs(6, 20, 31, seed=3, noise_px=1.0),
+    "wide_offsets_many_misses": lambda: encoder_msda_inputs(3, 24, 40, seed=4, noise_px=6.0),
+    "batch2": lambda: encoder_msda_inputs(4, 17, 19, B=2, seed=5),
+    "d32_16cams": lambda: encoder_msda_inputs(16, 9, 33, M=8, D=32, seed=6),
+    "single_level": lambda: encoder_msda_inputs(1, 30, 50, seed=7),
+    "m2": lambda: encoder_msda_inputs(5, 12, 18, M=2, D=16, seed=8),
+}
+
+
+@pytest.mark.parametrize("case", sorted(TILE_CASES))
+def test_tile_kernel_vs_gather_and_oracle(msda_impl, case):
+    args = TILE_CASES[case]()
+    tile, used = _fwd_impl(msda_impl, "tile", args)
+    assert used == "tile"
+    gather, used = _fwd_impl(msda_impl, "gather", args)
+    assert used == "gather"
+    ref = c_oracle.msda_forward(*[a.double() if a.is_floating_point() else a for a in args])
+    assert (tile.double() - ref).abs().max().item() < FP32_TOL
+    assert (gather.double() - ref).abs().max().item() < FP32_TOL
+    assert (tile - gather).abs().max().item() < 2e-5          # same taps, different summation order
+
+
+def test_tile_kernel_unequal_levels(msda_impl):
+    from helpers import pyramid_encoder_inputs
+    args = pyramid_encoder_inputs([(24, 36), (12, 18), (6, 9), (3, 5)], M=8, D=32, seed=9)
+    tile, used = _fwd_impl(msda_impl, "tile", args)
+    assert used == "tile"
+    ref = c_oracle.msda_forward(*[a.double() if a.is_floating_point() else a for a in args])
+    assert (tile.double() - ref).abs().max().item() < FP32_TOL
+    args = pyramid_encoder_inputs([(10, 37), (20, 11), (7, 7)], M=4, D=16, seed=10, noise_px=3.0)
+    tile, used = _fwd_impl(msda_impl, "tile", args)
+    assert used == "tile"
+    ref = c_oracle.msda_forward(*[a.double() if a.is_floating_point() else a for a in args])
+    assert (tile.double() - ref).abs().max().item() < FP32_TOL
+
+
+def test_tile_kernel_adversarial_and_edge_locations(msda_impl):
+    # uniform locations: nearly every tap leaves its window -> the deferred global path does the work
+    args = random_msda_inputs(1, [(40, 64)] * 3, 8, 16, 3 * 40 * 64, 4, seed=11, lo=-0.1, hi=1.1)
+    tile, used = _fwd_impl(msda_impl, "tile", args)
+    assert used == "tile"
+    ref = c_oracle.msda_forward(*[a.double() if a.is_floating_point() else a for a in args])
+    assert (tile.double() - ref).abs().max().item() < FP32_TOL
+    # NaN / inf / huge locations must take the guarded path, not index LDS
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(3, 16, 32, seed=12)
+    loc[0, 5] = float("nan")
+    loc[0, 6] = float("inf")
+    loc[0, 7] = -1e30
+    loc[0, 8, :, :, :, 0] = 1e30
+    tile, _ = _fwd_impl(msda_impl, "tile", (value, shapes, lsi, loc, aw))
+    ref = torch_oracle.msda_core(value, shapes, loc, aw)
+    keep = torch.ones(loc.shape[1], dtype=torch.bool)
+    keep[5:9] = False
+    assert (tile[0, keep] - ref[0, keep]).abs().max().item() < FP32_TOL
+    assert float(tile[0, 5:9].abs().max()) == 0.0
+
+
+def test_auto_dispatch_rules(msda_impl):
+    MSDA = msda_impl
+    MSDA.set_forward_impl("auto")
+    args = encoder_msda_inputs(7, 16, 24, seed=1)
+    MSDA.ms_deform_attn_forward(*dev(*args), 64)
+    assert MSDA.last_forward_impl() == "tile"
+    # decoder-style call (Lq != S), fp64, D = 30, P != 4: gather
+    for a in (random_msda_inputs(1, [(8, 8)], 8, 16, 10, 4),
+              [x.double() if x.is_floating_point() else x for x in args],
+              random_msda_inputs(1, [(4, 4)], 2, 30, 16, 4),
+              random_msda_inputs(1, [(4, 4)], 2, 16, 16, 3)):
+        MSDA.ms_deform_attn_forward(*dev(*a), 64)
+        assert MSDA.last_forward_impl() == "gather"
