@@ -32,11 +32,14 @@ constexpr int TILE_P = 4;
 
 template <int D, int TH_, int TW_, int R_> struct TileCfg {
     static constexpr int TH = TH_, TW = TW_, R = R_;
-    static constexpr int MH = 32 / D;                 // heads per 128-byte slice
-    static constexpr int SLICE = 32;                  // floats per token in LDS
+    static constexpr int SLICE = 32;                  // floats per token in LDS (128 bytes)
+    static constexpr int HPS = SLICE / D;             // heads per slice: 2 (D=16) or 1 (D=32)
+    static constexpr int SUBS = 2;                    // lanes per query: one per 64-byte half slice
     static constexpr int WH = TH + 2 * R, WW = TW + 2 * R;
-    static constexpr int THREADS = TH * TW * MH;
+    static constexpr int THREADS = TH * TW * SUBS;
     static constexpr int LDS_BYTES = WH * WW * SLICE * 4;
+    static_assert(D == 16 || D == 32, "a lane owns 16 channels: half of a 128-byte slice");
+    static_assert(THREADS / 8 >= WW, "window copy: one pass of THREADS/8 columns must cover a row");
 };
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
@@ -48,16 +51,23 @@ __device__ __forceinline__ int tiles_of_level(const int64_t *shapes, int l)
     return ((H + Cfg::TH - 1) / Cfg::TH) * ((W + Cfg::TW - 1) / Cfg::TW);
 }
 
-// XOR swizzle of the 16-byte chunk index inside a token's 128-byte LDS row.  A ds_read_b128 is
-// served in 16-lane groups over a 256-byte bank row; neighbouring queries read neighbouring tokens
-// (stride 128 B), so without it the 8 queries x MH heads of a group pile onto 4 (D=16) or 2 (D=32)
-// of the 16 slots (measured: 72 % of LDS cycles were conflict cycles).  XOR-ing with the token
-// index's bits [1..] spreads same-parity tokens over all slots of their head.
-template <int D> __device__ __forceinline__ int chunk_swizzle(int tok)
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// acc += w * c for 4 consecutive channels, written on 2-wide vectors so it lowers to v_pk_fma_f32
+__device__ __forceinline__ void fma4(float2v &lo, float2v &hi, float w, const float4 &c)
 {
-    return (tok >> 1) & (D / 4 - 1);
+    const float2v ww = {w, w};
+    lo = __builtin_elementwise_fma(ww, (float2v){c.x, c.y}, lo);
+    hi = __builtin_elementwise_fma(ww, (float2v){c.z, c.w}, hi);
 }
 
+// Bank conflicts.  A ds_read_b128 is served in 16-lane groups over a 256-byte bank row; neighbouring
+// queries read neighbouring tokens (128 B apart), so if every lane read chunk j of its head at step j
+// the 8 queries x 2 half-slices of a group would pile onto 4 (D=16) or 2 (D=32) of the 16 slots (measured:
+// 72 % of all LDS cycles were conflict cycles).  Instead lane (qx, head) reads chunk j ^ r at step j,
+// r = (qx >> 1) mod chunks-per-head: same-parity neighbours then cover all slots of their head.  r is a
+// per-lane constant, so accumulator j simply holds channels 4*(j^r) .. +3 for the whole kernel and only
+// the final store (and the rare global-memory taps) need to know.  The LDS image itself stays linear.
 template <int D, typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -65,12 +75,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
     int B, int S, int M, int L, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
-    constexpr int TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, MH = Cfg::MH;
-    constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = D / 4;
-    constexpr int NSTAGE = (WH * WW * 8 + Cfg::THREADS - 1) / Cfg::THREADS;   // float4 per thread per window
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, HPS = Cfg::HPS;
+    constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = 4;  // 4 x 16-byte chunks per lane
     const int tid = threadIdx.x;
-    const int HS = M / MH;                                // head slices per token row
-    const int64_t row = (int64_t)M * D;
+    const int HS = M / HPS;                               // 128-byte slices per token row
+    const int row = M * D;                                // floats per value token
 
     // ---- the tile list: [level][tile-in-level] x head slice x batch ------------------------------
     int tiles_spatial = 0;
@@ -80,48 +89,44 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
         equal_shapes = equal_shapes && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
     }
     const int per_level = equal_shapes ? tiles_spatial / L : 0;
-    const int64_t units = (int64_t)per_level * HS * B;   // (tile, slice, batch) units, equal shapes only
-    const int64_t units8 = (units + 7) / 8;               // units per XCD
+    const int units = per_level * HS * B;                 // (tile, slice, batch) units, equal shapes only
+    const int units8 = (units + 7) / 8;                   // units per XCD
     // equal shapes: t enumerates xcd x (unit of that xcd) x level, see the decode below
-    const int64_t total = equal_shapes ? units8 * 8 * L : (int64_t)tiles_spatial * HS * B;
+    const int total = equal_shapes ? units8 * 8 * L : tiles_spatial * HS * B;
 
-    const int hh = tid % MH;
-    const int qi = tid / MH;
+    const int sub = tid & 1;                              // which 64-byte half of the slice
+    const int qi = tid >> 1;
     const int qly = qi / TW, qlx = qi % TW;
+    const int rot = (qlx >> 1) & (NV - 1);                // this lane's chunk rotation
+    const int lane_off = sub * 16;                        // floats: this lane's 16 channels inside the slice
+    const int head_in_slice = D == 16 ? sub : 0;          // D=32: both halves belong to one head
+    const int ch_off = D == 16 ? 0 : sub * 16;            // ... and are its channels 0-15 / 16-31
 
-    // per-thread constants of the window copy: which float4s of the window this thread moves
-    int st_src[NSTAGE];      // (wy * 65536 + wx) * 8 + part, or -1
-    int st_dst[NSTAGE];      // float offset into win (swizzled)
-#pragma unroll
-    for (int i = 0; i < NSTAGE; ++i) {
-        const int idx = tid + i * Cfg::THREADS;
-        const int tok = idx >> 3, part = idx & 7;
-        const int wy = tok / WW, wx = tok - wy * WW;
-        st_src[i] = idx < WH * WW * 8 ? ((wy << 16) | wx) : -1;
-        st_dst[i] = tok * SLICE + ((part ^ chunk_swizzle<D>(tok)) << 2);
-    }
-    const int my_part = tid & 7;                          // idx & 7 is the same for every i (THREADS % 8 == 0)
+    // window copy: thread moves float4 `my_part` of window column `my_col`, one row per step
+    const int my_part = tid & 7, my_col = tid >> 3;
+    const bool col_ok = my_col < WW;
+    float *const st_dst = win + my_col * SLICE + my_part * 4;
 
-    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
-        // ---- decode t (wave-uniform) ------------------------------------------------------------
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        // ---- decode t (wave-uniform, scalar) -----------------------------------------------------
         int lq, tin, hs, b;
         if (equal_shapes) {
             // workgroups t, t+8, t+16, ... share an XCD (and its L2).  Give XCD k a contiguous band of
             // units, and run the L query levels of one unit back to back: their source windows are
             // identical, so all but the first find them in that L2.
-            const int64_t xcd = t & 7, r = t >> 3;
-            lq = (int)(r % L);
-            const int64_t unit = xcd * units8 + r / L;
+            const int xcd = t & 7, r = t >> 3;
+            lq = r % L;
+            const int unit = xcd * units8 + r / L;
             if (r / L >= units8 || unit >= units) continue;
-            hs = (int)(unit % HS);
-            const int64_t u2 = unit / HS;
-            tin = (int)(u2 % per_level);
-            b = (int)(u2 / per_level);
+            hs = unit % HS;
+            const int u2 = unit / HS;
+            tin = u2 % per_level;
+            b = u2 / per_level;
         } else {
-            hs = (int)(t % HS);
-            int64_t u2 = t / HS;
-            b = (int)(u2 / tiles_spatial);
-            int rem = (int)(u2 % tiles_spatial);
+            hs = t % HS;
+            const int u2 = t / HS;
+            b = u2 / tiles_spatial;
+            int rem = u2 % tiles_spatial;
             lq = 0;
             for (;; ++lq) {
                 const int n = tiles_of_level<Cfg>(shapes, lq);
@@ -133,46 +138,50 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
         const int Hq = (int)shapes[2 * lq], Wq = (int)shapes[2 * lq + 1];
         const int tcols = (Wq + TW - 1) / TW;
         const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
-        const int m0 = hs * MH;
+        const int m0 = hs * HPS;                           // first head of this slice
 
         const int qy = Y0 + qly, qx = X0 + qlx;
         const bool active = qy < Hq && qx < Wq;
         const int64_t q = lsi[lq] + (int64_t)qy * Wq + qx;          // query index == token index
-        const int64_t bqm = active ? (((int64_t)b * S + q) * M + m0 + hh) : 0;
+        const int64_t bqm = active ? (((int64_t)b * S + q) * M + m0 + head_in_slice) : 0;
         const float *lp = loc + bqm * L * P * 2;
         const float *wp = aw + bqm * L * P;
+        const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;   // this slice of token 0
 
-        float acc[D];
+        float2v acc[2 * NV];
 #pragma unroll
-        for (int i = 0; i < D; ++i) acc[i] = 0.f;
+        for (int i = 0; i < 2 * NV; ++i) acc[i] = (float2v){0.f, 0.f};
         unsigned long long miss = 0ull;
 
         // window geometry of a level: origin = the tile's centre carried to that level (integers)
         auto origin = [&](int l, int &oy, int &ox, int &H, int &W) {
             H = (int)shapes[2 * l];
             W = (int)shapes[2 * l + 1];
-            oy = (int)(((int64_t)(2 * Y0 + TH) * H) / (2 * Hq)) - WH / 2;
-            ox = (int)(((int64_t)(2 * X0 + TW) * W) / (2 * Wq)) - WW / 2;
+            oy = (2 * Y0 + TH) * H / (2 * Hq) - WH / 2;
+            ox = (2 * X0 + TW) * W / (2 * Wq) - WW / 2;
         };
-        // issue this thread's share of a window copy into registers (loads stay in flight)
-        float4 stage[NSTAGE];
+        // issue this thread's share of a window copy into registers (loads stay in flight): its
+        // column, one row per step -- the row index and its bounds test are wave-uniform
+        float4 stage[WH];
         auto fetch_window = [&](int l) {
             int oy, ox, H, W;
             origin(l, oy, ox, H, W);
-            const float *plane = value + ((int64_t)b * S + lsi[l]) * row + (int64_t)m0 * D + my_part * 4;
+            const int gx = ox + my_col;
+            const bool xok = col_ok && (unsigned)gx < (unsigned)W;
+            const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
 #pragma unroll
-            for (int i = 0; i < NSTAGE; ++i) {
-                const int gy = oy + (st_src[i] >> 16), gx = ox + (st_src[i] & 0xffff);
+            for (int i = 0; i < WH; ++i) {
+                const int gy = oy + i;
                 stage[i] = make_float4(0, 0, 0, 0);
-                if (st_src[i] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    stage[i] = *reinterpret_cast<const float4 *>(plane + ((int64_t)gy * W + gx) * row);
+                if (xok && (unsigned)gy < (unsigned)H)
+                    stage[i] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * W * row);
             }
         };
 
         // ---- locality probe: do this tile's taps stay near their own cell? ------------------------
         // Sampling data of the first level doubles as the probe.  If fewer than a quarter of the
-        // workgroup's taps of that level fall inside the window, staging would be wasted: the tile is
-        // then done entirely by the direct path below (all bits set in `miss`).
+        // workgroup's lanes have most of that level's taps inside the window, staging would be
+        // wasted: the tile is then done entirely by the direct path below (all bits set in `miss`).
         float4 la = make_float4(0, 0, 0, 0), lb = la, wa = la;
         if (active) {
             la = *reinterpret_cast<const float4 *>(lp);
@@ -183,16 +192,16 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
         {
             int oy, ox, H, W;
             origin(0, oy, ox, H, W);
+            const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
             const float xs[4] = {la.x, la.z, lb.x, lb.z}, ys[4] = {la.y, la.w, lb.y, lb.w};
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const float x = xs[p] * (float)W - 0.5f, y = ys[p] * (float)H - 0.5f;
-                hits += (active && x >= (float)ox && x < (float)(ox + WW - 1) && y >= (float)oy &&
-                         y < (float)(oy + WH - 1)) ? 1 : 0;
+                hits += (active && fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) ? 1 : 0;
             }
         }
         const int live = __syncthreads_count(active);
-        const int tile_hits = __syncthreads_count(hits >= 2);       // threads with most taps inside
+        const int tile_hits = __syncthreads_count(hits >= 2);
         const bool staged = 4 * tile_hits >= live;
 
         if (staged) {
@@ -201,9 +210,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
                 int oy, ox, H, W;
                 origin(l, oy, ox, H, W);
                 __syncthreads();                          // everyone is done reading the old window
+                if (col_ok) {
 #pragma unroll
-                for (int i = 0; i < NSTAGE; ++i)
-                    if (st_src[i] >= 0) *reinterpret_cast<float4 *>(win + st_dst[i]) = stage[i];
+                    for (int i = 0; i < WH; ++i)
+                        *reinterpret_cast<float4 *>(st_dst + i * WW * SLICE) = stage[i];
+                }
                 // next level: window copy and sampling data go in flight under this level's taps
                 float4 na = la, nb = lb, nw = wa;
                 if (l + 1 < L) {
@@ -220,39 +231,40 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
                     const float lxs[4] = {la.x, la.z, lb.x, lb.z};
                     const float lys[4] = {la.y, la.w, lb.y, lb.w};
                     const float aws[4] = {wa.x, wa.y, wa.z, wa.w};
-                    const float oxf = (float)ox, oyf = (float)oy;
+                    const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
+                    const float fW = (float)W, fH = (float)H;
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
-                        const float x = lxs[p] * (float)W - 0.5f;
-                        const float y = lys[p] * (float)H - 0.5f;
-                        const bool inwin = x >= oxf && x < oxf + (float)(WW - 1) && y >= oyf &&
-                                           y < oyf + (float)(WH - 1);
-                        if (inwin) {
+                        const float x = lxs[p] * fW - 0.5f;
+                        const float y = lys[p] * fH - 0.5f;
+                        // footprint [floor, floor+1] inside the window <=> |x - centre| < (WW-1)/2
+                        // (false for NaN/inf; the window border itself counts as outside)
+                        if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
                             const float fx = floorf(x), fy = floorf(y);
                             const int ix = (int)fx - ox, iy = (int)fy - oy;
-                            const float wx1 = x - fx, wy1 = y - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                            const float wx1 = x - fx, wy1 = y - fy;
                             const float a = aws[p];
-                            const float w00 = wy0 * wx0 * a, w01 = wy0 * wx1 * a;
-                            const float w10 = wy1 * wx0 * a, w11 = wy1 * wx1 * a;
-                            const int t00 = iy * WW + ix;
-                            const float *p00 = win + t00 * SLICE + hh * D;
-                            const float *p10 = p00 + WW * SLICE;
-                            const int s00 = chunk_swizzle<D>(t00), s01 = chunk_swizzle<D>(t00 + 1);
-                            const int s10 = chunk_swizzle<D>(t00 + WW), s11 = chunk_swizzle<D>(t00 + WW + 1);
+                            const float ay1 = wy1 * a, ay0 = a - ay1;                 // (1 - wy1) * a
+                            const float w01 = ay0 * wx1, w00 = ay0 - w01;
+                            const float w11 = ay1 * wx1, w10 = ay1 - w11;
+                            const float *p00 = win + __mul24(iy * WW + ix, SLICE) + lane_off;
 #pragma unroll
                             for (int k = 0; k < NV; ++k) {
-                                const float4 c00 = *reinterpret_cast<const float4 *>(p00 + ((k ^ s00) << 2));
-                                const float4 c01 = *reinterpret_cast<const float4 *>(p00 + SLICE + ((k ^ s01) << 2));
-                                const float4 c10 = *reinterpret_cast<const float4 *>(p10 + ((k ^ s10) << 2));
-                                const float4 c11 = *reinterpret_cast<const float4 *>(p10 + SLICE + ((k ^ s11) << 2));
-                                acc[4 * k + 0] += w00 * c00.x + w01 * c01.x + w10 * c10.x + w11 * c11.x;
-                                acc[4 * k + 1] += w00 * c00.y + w01 * c01.y + w10 * c10.y + w11 * c11.y;
-                                acc[4 * k + 2] += w00 * c00.z + w01 * c01.z + w10 * c10.z + w11 * c11.z;
-                                acc[4 * k + 3] += w00 * c00.w + w01 * c01.w + w10 * c10.w + w11 * c11.w;
+                                const float *pk = p00 + ((k ^ rot) << 2);
+                                const float4 c00 = *reinterpret_cast<const float4 *>(pk);
+                                const float4 c01 = *reinterpret_cast<const float4 *>(pk + SLICE);
+                                const float4 c10 = *reinterpret_cast<const float4 *>(pk + WW * SLICE);
+                                const float4 c11 = *reinterpret_cast<const float4 *>(pk + WW * SLICE + SLICE);
+                                fma4(acc[2 * k], acc[2 * k + 1], w00, c00);
+                                fma4(acc[2 * k], acc[2 * k + 1], w01, c01);
+                                fma4(acc[2 * k], acc[2 * k + 1], w10, c10);
+                                fma4(acc[2 * k], acc[2 * k + 1], w11, c11);
                             }
                         } else {
                             miss |= 1ull << (l * P + p);
                         }
+                        // keep the taps apart: hoisting all 4 x 16 LDS reads together costs > 256 VGPRs
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 la = na;
@@ -275,29 +287,29 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
                 const float a = wp[bit];
                 if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
                 const Footprint<float> f = footprint(y, x, H, W);
-                const float *r0 = value + ((int64_t)b * S + lsi[l]) * row + (int64_t)(m0 + hh) * D +
-                                  ((int64_t)f.y0 * W + f.x0) * row;
+                const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * W + f.x0) * row;
                 const float *r1 = r0 + (int64_t)W * row;
                 const float w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a;
                 const float w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
+                    const int ko = (k ^ rot) << 2;
                     const float4 z = make_float4(0, 0, 0, 0);
-                    const float4 c00 = (f.vy0 && f.vx0) ? *reinterpret_cast<const float4 *>(r0 + 4 * k) : z;
-                    const float4 c01 = (f.vy0 && f.vx1) ? *reinterpret_cast<const float4 *>(r0 + row + 4 * k) : z;
-                    const float4 c10 = (f.vy1 && f.vx0) ? *reinterpret_cast<const float4 *>(r1 + 4 * k) : z;
-                    const float4 c11 = (f.vy1 && f.vx1) ? *reinterpret_cast<const float4 *>(r1 + row + 4 * k) : z;
-                    acc[4 * k + 0] += w00 * c00.x + w01 * c01.x + w10 * c10.x + w11 * c11.x;
-                    acc[4 * k + 1] += w00 * c00.y + w01 * c01.y + w10 * c10.y + w11 * c11.y;
-                    acc[4 * k + 2] += w00 * c00.z + w01 * c01.z + w10 * c10.z + w11 * c11.z;
-                    acc[4 * k + 3] += w00 * c00.w + w01 * c01.w + w10 * c10.w + w11 * c11.w;
+                    const float4 c00 = (f.vy0 && f.vx0) ? *reinterpret_cast<const float4 *>(r0 + ko) : z;
+                    const float4 c01 = (f.vy0 && f.vx1) ? *reinterpret_cast<const float4 *>(r0 + row + ko) : z;
+                    const float4 c10 = (f.vy1 && f.vx0) ? *reinterpret_cast<const float4 *>(r1 + ko) : z;
+                    const float4 c11 = (f.vy1 && f.vx1) ? *reinterpret_cast<const float4 *>(r1 + row + ko) : z;
+                    fma4(acc[2 * k], acc[2 * k + 1], w00, c00);
+                    fma4(acc[2 * k], acc[2 * k + 1], w01, c01);
+                    fma4(acc[2 * k], acc[2 * k + 1], w10, c10);
+                    fma4(acc[2 * k], acc[2 * k + 1], w11, c11);
                 }
             }
-            float *o = out + bqm * D;
+            float *o = out + bqm * D + ch_off;
 #pragma unroll
             for (int k = 0; k < NV; ++k)
-                *reinterpret_cast<float4 *>(o + 4 * k) =
-                    make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+                *reinterpret_cast<float4 *>(o + ((k ^ rot) << 2)) =
+                    make_float4(acc[2 * k].x, acc[2 * k].y, acc[2 * k + 1].x, acc[2 * k + 1].y);
         }
     }
 }
@@ -308,8 +320,8 @@ using Cfg32 = TileCfg<32, 8, 16, 6>;
 bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16)
 {
     if (!aligned16 || P != TILE_P || L > TILE_MAX_LEVELS || Lq != S || B < 1) return false;
-    if (D == 16) return M % Cfg16::MH == 0;
-    if (D == 32) return M % Cfg32::MH == 0;
+    if (D == 16) return M % Cfg16::HPS == 0;
+    if (D == 32) return M % Cfg32::HPS == 0;
     return false;
 }
 

@@ -1,0 +1,122 @@
+"""Multi-GPU execution of the fusion path: one process per GPU, torch.distributed over RCCL/xGMI
+(backend "nccl" is RCCL on ROCm; "gloo" on CPU for the tests).
+
+The reference has no distributed code at all (single process, one .cuda() device).
+Two ways the path shards:
+
+  * frames (batch) are independent -> replicas, NO data-path collective ("dp");
+  * cameras are independent up to the shadow transformer: backbone, heads, warp and the stride-2
+    token conv run per view; every rank then needs the tokens of ALL views as attention `value`
+    -> exactly ONE all-gather of per-view world tokens per frame ("views").  The payload per view is
+    h*w*C fp32 = 5.5 MB at Wildtrack size; over fully connected xGMI RCCL uses a direct exchange for
+    that size.  The encoder is replicated after the gather.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment; initialises the default process
+    group when WORLD_SIZE > 1 (nccl == RCCL when a GPU is present, gloo otherwise)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        use_gpu = torch.cuda.is_available()
+        if use_gpu:
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def partition_views(num_views: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [start, end) view ranges per rank, sizes differing by at most one, larger shards
+    first (7 views / 8 ranks -> seven ranks with one view, rank 7 idle; 16 / 8 -> two each)."""
+    base, extra = divmod(num_views, world)
+    out, start = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=None) -> torch.Tensor:
+    """local_tokens [B, n_local*hw, C] (this rank's views, possibly none) -> [B, num_views*hw, C] on
+    every rank, views in camera order.  One all_gather_into_tensor; ragged shards are padded to the
+    largest shard and the padding is dropped after the collective.  Inference only: the collective is
+    not differentiable (the tokens are detached)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_tokens
+    rank = dist.get_rank(group)
+    parts = partition_views(num_views, world)
+    B, _, C = local_tokens.shape
+    n_max = max(e - s for s, e in parts)
+    n_loc = parts[rank][1] - parts[rank][0]
+    hw = local_tokens.shape[1] // n_loc if n_loc else None
+    # every rank must agree on hw; ranks without a view learn it from the others via a tiny all-reduce
+    hw_t = torch.tensor([hw or 0], device=local_tokens.device, dtype=torch.int64)
+    if any(e == s for s, e in parts):
+        dist.all_reduce(hw_t, op=dist.ReduceOp.MAX, group=group)
+    hw = int(hw_t.item())
+    with torch.no_grad():
+        send = local_tokens.new_zeros(B, n_max * hw, C)
+        if n_loc:
+            send[:, :n_loc * hw] = local_tokens.detach()
+        # concatenated-along-dim-0 form: accepted by both RCCL and gloo
+        recv = local_tokens.new_empty(world * B, n_max * hw, C)
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
+    recv = recv.view(world, B, n_max * hw, C)
+    pieces = [recv[r, :, :(e - s) * hw] for r, (s, e) in enumerate(parts) if e > s]
+    return torch.cat(pieces, dim=1)
+
+
+class ViewShardedFrame:
+    """Runs one frame with the cameras partitioned over the ranks of `group`."""
+
+    def __init__(self, model, group=None):
+        self.model, self.group = model, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.range = partition_views(model.num_cam, self.world)[self.rank]
+
+    @torch.no_grad()
+    def __call__(self, imgs_local, M):
+        """imgs_local [B, n_local, 3, H, W]: this rank's cameras only; M [B, N, 3, 3] for all cameras.
+        Returns (world_heatmap, world_offset), identical on every rank."""
+        m = self.model
+        s, e = self.range
+        B = M.shape[0]
+        H, W = m.Rworld_shape
+        wf = m.world_feat
+        h, w = H // wf.stride, W // wf.stride
+        if e > s:
+            proj = m.frame_proj_mats(M).view(B, m.num_cam, 3, 3)[:, s:e].reshape(-1, 3, 3)
+            feat = m.features(imgs_local)
+            from .ops import warp_perspective
+            world = warp_perspective(feat, proj.to(feat.device, non_blocking=True), (H, W), channels_last_out=True)
+            local, h, w = wf.tokens(world.view(B, e - s, H, W, -1))
+        else:
+            dev = next(m.parameters()).device
+            local = torch.zeros(B, 0, wf.hidden_dim, device=dev)
+        tokens = all_gather_view_tokens(local, m.num_cam, self.group)
+        fused = wf.fuse(tokens, B, h, w)
+        return m.world_heatmap(fused), m.world_offset(fused)
+
+
+def barrier_and_max(elapsed_s: float, device) -> float:
+    """Max of a per-rank wall time over all ranks (the bench contract's timing rule)."""
+    if not dist.is_initialized():
+        return elapsed_s
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

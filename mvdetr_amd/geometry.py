@@ -87,7 +87,14 @@ STRESS16 = SceneGeometry(
     worldcoord_from_worldgrid_mat=np.array([[2.5, 0, -300], [0, 2.5, -900], [0, 0, 1.0]]),
     img_reduce=8, feat_channels=256)
 
-GEOMETRIES = {g.name: g for g in (WILDTRACK, MULTIVIEWX, STRESS16)}
+# small scene for tests / smoke runs: 3 cameras, 144x256 inputs, 32-channel features, 24x72 world grid
+MINI = SceneGeometry(
+    name="mini", num_cam=3, img_shape=(216, 384), worldgrid_shape=(96, 288),
+    indexing="ij", worldcoord_unit=0.01,
+    worldcoord_from_worldgrid_mat=np.array([[12.5, 0, -300], [0, 12.5, -900], [0, 0, 1.0]]),
+    feat_channels=32)
+
+GEOMETRIES = {g.name: g for g in (WILDTRACK, MULTIVIEWX, STRESS16, MINI)}
 
 
 def project_2d_points(project_mat: np.ndarray, pts: np.ndarray) -> np.ndarray:
@@ -116,7 +123,8 @@ def synthetic_rig(geom: SceneGeometry, seed: int = 0) -> Tuple[List[np.ndarray],
     """
     rng = np.random.default_rng(seed)
     H, W = geom.img_shape
-    K = np.array([[1743.0, 0, W / 2.0], [0, 1743.0, H / 2.0], [0, 0, 1.0]])
+    f = 1743.0 * W / 1920.0
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1.0]])
     # extent of the plane in world coordinates (grid corner (0,0) and (N_row, N_col))
     g = geom.worldcoord_from_worldgrid_mat
     n0, n1 = geom.worldgrid_shape if geom.indexing == "ij" else geom.worldgrid_shape[::-1]

@@ -1,0 +1,159 @@
+"""Minimal caller of the fusion path: an MVDeTr-shaped detector whose warp and deformable attention
+run on the HIP kernels.  Everything that is not the hot path (ResNet-18 trunk, heads) is ordinary
+PyTorch-ROCm, as in the reference.
+
+Mirrors multiview_detector/models/mvdetr.py:74-218 (constructor arithmetic, forward order, output
+tuple) and the dilated ResNet-18 trunk of multiview_detector/models/resnet.py:33-70,120-186
+(``replace_stride_with_dilation=[False, True, True]``, children()[:-2] -> stride 8, 512 channels;
+parameter names follow ``base.<child index>...`` so reference checkpoints line up).  Weights are
+seeded random: there is no network for the pretrained download (resnet.py:213-216).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import geometry
+from .ops import warp_perspective
+from .world_feat import ConvWorldFeat, DeformTransWorldFeat
+
+
+class BasicBlock(nn.Module):
+    """3x3-3x3 residual block; only the FIRST conv is dilated (resnet.py:46-51 of the fork)."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+def resnet18_trunk(replace_stride_with_dilation=(False, True, True), in_channels=3) -> nn.Sequential:
+    """conv1, bn1, relu, maxpool, layer1..4 as one Sequential (the reference slices
+    list(resnet18(...).children())[:-2], mvdetr.py:103-105)."""
+    state = {"inplanes": 64, "dilation": 1}
+
+    def make_layer(planes, blocks, stride=1, dilate=False):
+        prev = state["dilation"]
+        if dilate:
+            state["dilation"] *= stride
+            stride = 1
+        down = None
+        if stride != 1 or state["inplanes"] != planes:
+            down = nn.Sequential(nn.Conv2d(state["inplanes"], planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [BasicBlock(state["inplanes"], planes, stride, down, prev)]
+        state["inplanes"] = planes
+        layers += [BasicBlock(planes, planes, dilation=state["dilation"]) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    trunk = nn.Sequential(
+        nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+        nn.MaxPool2d(3, 2, 1),
+        make_layer(64, 2), make_layer(128, 2, 2, replace_stride_with_dilation[0]),
+        make_layer(256, 2, 2, replace_stride_with_dilation[1]), make_layer(512, 2, 2, replace_stride_with_dilation[2]))
+    for m in trunk.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    return trunk
+
+
+def output_head(in_dim, feat_dim, out_dim):
+    # mvdetr.py:24-30
+    if feat_dim:
+        return nn.Sequential(nn.Conv2d(in_dim, feat_dim, 3, padding=1), nn.ReLU(), nn.Conv2d(feat_dim, out_dim, 1))
+    return nn.Sequential(nn.Conv2d(in_dim, out_dim, 1))
+
+
+class MVDeTr(nn.Module):
+    def __init__(self, geom: geometry.SceneGeometry, Ks, Rts, arch="resnet18", z=0, world_feat_arch="deform_trans",
+                 bottleneck_dim=None, outfeat_dim=0, dropout=0.5, channels_last=True):
+        super().__init__()
+        self.geom = geom
+        self.Rimg_shape, self.Rworld_shape = geom.Rimg_shape, geom.Rworld_shape
+        self.img_reduce, self.num_cam = geom.img_reduce, geom.num_cam
+        self.channels_last = channels_last
+        bottleneck_dim = geom.feat_channels if bottleneck_dim is None else bottleneck_dim
+        # image pixel -> reduced world grid, fp64 (mvdetr.py:82-95)
+        self.register_buffer("proj_mats", torch.from_numpy(geometry.build_proj_mats(geom, Ks, Rts, z)), persistent=False)
+        if arch != "resnet18":
+            raise ValueError("the minimal caller wires ResNet-18 only (the reference: vgg11/resnet18)")
+        self.base = resnet18_trunk()
+        base_dim = 512
+        if bottleneck_dim:
+            self.bottleneck = nn.Sequential(nn.Conv2d(base_dim, bottleneck_dim, 1), nn.Dropout2d(dropout))
+            base_dim = bottleneck_dim
+        else:
+            self.bottleneck = nn.Identity()
+        self.img_heatmap = output_head(base_dim, outfeat_dim, 1)
+        self.img_offset = output_head(base_dim, outfeat_dim, 2)
+        self.img_wh = output_head(base_dim, outfeat_dim, 2)
+        self.world_feat_arch = world_feat_arch
+        if world_feat_arch == "deform_trans":
+            n_points = 4
+            ref = geometry.create_reference_map(geom, Ks, Rts, n_points).repeat([geom.num_cam, 1, 1, 1])
+            self.world_feat = DeformTransWorldFeat(geom.num_cam, geom.Rworld_shape, base_dim, hidden_dim=base_dim,
+                                                   n_points=n_points, stride=2, reference_points=ref)
+        elif world_feat_arch == "conv":
+            self.world_feat = ConvWorldFeat(geom.num_cam, geom.Rworld_shape, base_dim, hidden_dim=base_dim)
+        else:
+            raise ValueError("world_feat_arch must be 'deform_trans' or 'conv'")
+        self.world_heatmap = output_head(base_dim, outfeat_dim, 1)
+        self.world_offset = output_head(base_dim, outfeat_dim, 2)
+        # init (mvdetr.py:142-148)
+        self.img_heatmap[-1].bias.data.fill_(-2.19)
+        self.world_heatmap[-1].bias.data.fill_(-2.19)
+        for head in (self.img_offset, self.img_wh, self.world_offset):
+            for m in head.modules():
+                if isinstance(m, nn.Conv2d) and m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def frame_proj_mats(self, M):
+        """[B*N,3,3] fp32 reduced world grid <- feature pixel, composed on the host in fp32 exactly like
+        mvdetr.py:155-161 (M is the dataloader's augmentation matrix and lives on the CPU there)."""
+        return geometry.compose_frame_proj_mats(self.proj_mats.cpu(), M.cpu(), self.img_reduce)
+
+    def features(self, imgs):
+        B, N, C, H, W = imgs.shape
+        x = imgs.reshape(B * N, C, H, W)
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        return self.bottleneck(self.base(x))
+
+    def forward(self, imgs, M, visualize=False):
+        B, N = imgs.shape[:2]
+        proj = self.frame_proj_mats(M)
+        feat = self.features(imgs)                                         # [B*N, C, h, w]
+        imgs_heatmap, imgs_offset, imgs_wh = self.img_heatmap(feat), self.img_offset(feat), self.img_wh(feat)
+        H, W = self.Rworld_shape
+        C = feat.shape[1]
+        nhwc = self.channels_last and self.world_feat_arch == "deform_trans"
+        world = warp_perspective(feat, proj.to(feat.device, non_blocking=True), (H, W), channels_last_out=nhwc)
+        world = world.view(B, N, H, W, C) if nhwc else world.view(B, N, C, H, W)
+        world = self.world_feat(world)
+        return (self.world_heatmap(world), self.world_offset(world)), (imgs_heatmap, imgs_offset, imgs_wh)
+
+    def hot_path(self, feat, proj):
+        """warp + shadow transformer only (the path BASELINE.json's north_star names), for timing."""
+        H, W = self.Rworld_shape
+        N = self.num_cam
+        B = feat.shape[0] // N
+        nhwc = self.channels_last and self.world_feat_arch == "deform_trans"
+        world = warp_perspective(feat, proj, (H, W), channels_last_out=nhwc)
+        world = world.view(B, N, H, W, -1) if nhwc else world.view(B, N, -1, H, W)
+        return self.world_feat(world)
+
+
+def build_model(config="wildtrack", seed=0, world_feat_arch="deform_trans", **kw) -> MVDeTr:
+    geom = geometry.GEOMETRIES[config]
+    Ks, Rts = geometry.synthetic_rig(geom, seed=seed)
+    torch.manual_seed(seed)
+    return MVDeTr(geom, Ks, Rts, world_feat_arch=world_feat_arch, **kw)

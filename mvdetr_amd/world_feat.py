@@ -140,15 +140,20 @@ class DeformTransWorldFeat(nn.Module):
         tok = y.permute(0, 2, 3, 1).reshape(B, N * h * w, self.hidden_dim)   # free if y is channels_last
         return tok, h, w
 
-    def forward(self, x, visualize=False):
-        B, N = x.shape[:2]
-        src, h, w = self.tokens(x)
-        C = self.hidden_dim
+    def fuse(self, src, B, h, w):
+        """[B, N*h*w, C] tokens of ALL cameras -> merged BEV feature [B, C, H, W]: level/position
+        embedding, 3 deformable encoder layers, per-camera 1x1 merge, upsample (trans_world_feat.py:93-110).
+        Split from tokens() so a view-sharded run can all-gather between the two (mvdetr_amd/dist.py)."""
+        N, C = self.num_cam, self.hidden_dim
         pos = self.pos_embedding.flatten(2).transpose(1, 2).unsqueeze(1)                 # [1,1,hw,C]
         lvl_pos = (pos + self.lvl_embedding.view(1, N, 1, C)).reshape(1, N * h * w, C)   # any B
         memory = self.encoder(src, self.spatial_shapes, self.level_start_index, None, lvl_pos)
         merged = memory.view(B, N, h, w, C).permute(0, 1, 4, 2, 3).reshape(B, N * C, h, w)
         return self.upsample(self.merge_linear(merged))
+
+    def forward(self, x, visualize=False):
+        src, h, w = self.tokens(x)
+        return self.fuse(src, x.shape[0], h, w)
 
 
 class ConvWorldFeat(nn.Module):

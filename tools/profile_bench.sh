@@ -1,0 +1,45 @@
+#!/bin/bash
+# Profiles `python bench.py` with rocprofv3 on the GPU box and writes the judged summaries under
+# gpurun_out/profile_<tag>/ (copy them into profiles/ afterwards):
+#   <tag>_kernel_stats.txt    per-kernel calls / avg / min / max us            (--kernel-trace --stats)
+#   <tag>_pmc_*.txt           per-kernel PMC averages, one pass per counter group (--pmc only)
+#   <tag>_traffic.json        HBM-side bytes per MSDA-forward launch: (2*FETCH_SIZE + WRITE_SIZE)*1024
+# usage: bash tools/profile_bench.sh r01 [bench args...]
+TAG=${1:-r01}; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/profile_$TAG
+mkdir -p $O
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline $@"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench.py $ARGS > $O/bench_under_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $O/pmc_fetch -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $O/pmc_write -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_sq -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_sq.log 2>&1
+cd $R
+python tools/rocpd_summary.py $O/trace/t_results.db > $O/${TAG}_kernel_stats.txt
+python tools/rocpd_summary.py $O/pmc_fetch/p_results.db --filter mvdetr > $O/${TAG}_pmc_fetch.txt
+python tools/rocpd_summary.py $O/pmc_write/p_results.db --filter mvdetr > $O/${TAG}_pmc_write.txt
+python tools/rocpd_summary.py $O/pmc_sq/p_results.db --filter mvdetr > $O/${TAG}_pmc_sq.txt
+python - <<PY
+import json, sqlite3
+def avg(db, counter, kern):
+    cur = sqlite3.connect(db).cursor()
+    v = [r[0] for r in cur.execute("select value from counters_collection where counter_name=? and kernel_name like ?", (counter, f"%{kern}%"))]
+    return sum(v) / len(v) if v else None
+out = {}
+for kern, key in (("msda_fwd", "msda_fwd"), ("warp_fwd", "warp_fwd")):
+    f = avg("$O/pmc_fetch/p_results.db", "FETCH_SIZE", kern)
+    w = avg("$O/pmc_write/p_results.db", "WRITE_SIZE", kern)
+    if f is not None and w is not None:
+        out[key + "_fetch_size_kb_raw"] = f
+        out[key + "_write_size_kb"] = w
+        out[key + "_bytes_per_launch"] = int((2 * f + w) * 1024)
+out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over: python bench.py $ARGS; "
+               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane "
+               "reads (MI355X_MICROARCH.md, HBM section; re-checked here on a device copy of known size), WRITE_SIZE is exact. "
+               "Infinity-Cache hits are included, so this is an upper bound on HBM bytes.")
+json.dump(out, open("$O/${TAG}_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_sq
+ls -la $O
