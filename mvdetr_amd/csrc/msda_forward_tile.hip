@@ -24,22 +24,33 @@
 // (multiview_detector/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299).
 #include "common.h"
 #include "msda_dispatch.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace mvdetr {
 
 constexpr int TILE_MAX_LEVELS = 16;     // 64-bit miss mask = L * P bits with P == 4
 constexpr int TILE_P = 4;
 
-template <int D, int TH_, int TW_, int R_> struct TileCfg {
-    static constexpr int TH = TH_, TW = TW_, R = R_;
-    static constexpr int SLICE = 32;                  // floats per token in LDS (128 bytes)
-    static constexpr int HPS = SLICE / D;             // heads per slice: 2 (D=16) or 1 (D=32)
-    static constexpr int SUBS = 2;                    // lanes per query: one per 64-byte half slice
+template <int D_, int SLICE_, int TH_, int TW_, int R_> struct TileCfg {
+    static constexpr int D = D_, TH = TH_, TW = TW_, R = R_;
+    static constexpr int SLICE = SLICE_;              // floats of a token row staged per workgroup (32 = 128 B, 16 = 64 B)
+    static constexpr int SUBS = 2;                    // lanes per query, each owning half a slice
+    static constexpr int NV = SLICE / SUBS / 4;       // 16-byte chunks (float4 accumulators) per lane
+    static constexpr int PARTS = SLICE / 4;           // float4 per token in LDS
     static constexpr int WH = TH + 2 * R, WW = TW + 2 * R;
     static constexpr int THREADS = TH * TW * SUBS;
+    static constexpr int COLSLOTS = THREADS / PARTS;  // window columns a copy pass covers ...
+    static constexpr int ROWS_PER_PASS = COLSLOTS / WW;   // ... i.e. this many whole rows
+    static constexpr int NSTAGE = (WH + ROWS_PER_PASS - 1) / ROWS_PER_PASS;   // float4 per lane per window
     static constexpr int LDS_BYTES = WH * WW * SLICE * 4;
-    static_assert(D == 16 || D == 32, "a lane owns 16 channels: half of a 128-byte slice");
-    static_assert(THREADS / 8 >= WW, "window copy: one pass of THREADS/8 columns must cover a row");
+    static constexpr int TOK_PER_BANKROW = 256 / (SLICE * 4);                 // tokens per 256-byte LDS bank row
+    // workgroups per CU the LDS admits; the register allocation is capped to match (waves per SIMD)
+    static constexpr int WGS_PER_CU = (160 * 1024) / LDS_BYTES;
+    static constexpr int WAVES_PER_SIMD = WGS_PER_CU * (THREADS / 64) / 4;
+    static_assert(SLICE == 16 || SLICE == 32, "64- or 128-byte slices");
+    static_assert(D % (SLICE / SUBS) == 0, "a lane's channels must lie inside one head");
+    static_assert(ROWS_PER_PASS >= 1, "window copy: one pass must cover at least one row");
 };
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
@@ -68,17 +79,17 @@ __device__ __forceinline__ void fma4(float2v &lo, float2v &hi, float w, const fl
 // r = (qx >> 1) mod chunks-per-head: same-parity neighbours then cover all slots of their head.  r is a
 // per-lane constant, so accumulator j simply holds channels 4*(j^r) .. +3 for the whole kernel and only
 // the final store (and the rare global-memory taps) need to know.  The LDS image itself stays linear.
-template <int D, typename Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
+template <typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
     int B, int S, int M, int L, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
-    constexpr int TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, HPS = Cfg::HPS;
-    constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = 4;  // 4 x 16-byte chunks per lane
+    constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
+    constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = Cfg::NV, NSTAGE = Cfg::NSTAGE, LCH = SLICE / 2;
     const int tid = threadIdx.x;
-    const int HS = M / HPS;                               // 128-byte slices per token row
+    const int HS = M * D / SLICE;                         // slices per token row
     const int row = M * D;                                // floats per value token
 
     // ---- the tile list: [level][tile-in-level] x head slice x batch ------------------------------
@@ -94,18 +105,18 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
     // equal shapes: t enumerates xcd x (unit of that xcd) x level, see the decode below
     const int total = equal_shapes ? units8 * 8 * L : tiles_spatial * HS * B;
 
-    const int sub = tid & 1;                              // which 64-byte half of the slice
+    const int sub = tid & 1;                              // which half of the slice this lane owns
     const int qi = tid >> 1;
     const int qly = qi / TW, qlx = qi % TW;
-    const int rot = (qlx >> 1) & (NV - 1);                // this lane's chunk rotation
-    const int lane_off = sub * 16;                        // floats: this lane's 16 channels inside the slice
-    const int head_in_slice = D == 16 ? sub : 0;          // D=32: both halves belong to one head
-    const int ch_off = D == 16 ? 0 : sub * 16;            // ... and are its channels 0-15 / 16-31
+    // chunk rotation: lanes whose tokens share a position inside the 256-byte bank row differ in r
+    const int rot = (qlx / Cfg::TOK_PER_BANKROW) & (NV - 1);
+    const int lane_off = sub * LCH;                       // floats: this lane's channels inside the slice
 
-    // window copy: thread moves float4 `my_part` of window column `my_col`, one row per step
-    const int my_part = tid & 7, my_col = tid >> 3;
-    const bool col_ok = my_col < WW;
-    float *const st_dst = win + my_col * SLICE + my_part * 4;
+    // window copy: thread moves float4 `my_part` of window column `my_col`, rows my_row0 + i*ROWS_PER_PASS
+    const int my_part = tid % Cfg::PARTS, my_slot = tid / Cfg::PARTS;
+    const int my_row0 = my_slot / WW, my_col = my_slot % WW;
+    const bool slot_ok = my_row0 < Cfg::ROWS_PER_PASS;
+    float *const st_dst = win + (my_row0 * WW + my_col) * SLICE + my_part * 4;
 
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         // ---- decode t (wave-uniform, scalar) -----------------------------------------------------
@@ -138,12 +149,13 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
         const int Hq = (int)shapes[2 * lq], Wq = (int)shapes[2 * lq + 1];
         const int tcols = (Wq + TW - 1) / TW;
         const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
-        const int m0 = hs * HPS;                           // first head of this slice
+        const int ch0 = hs * SLICE + lane_off;              // this lane's first channel in the token row
+        const int head = ch0 / D, ch_off = ch0 % D;
 
         const int qy = Y0 + qly, qx = X0 + qlx;
         const bool active = qy < Hq && qx < Wq;
         const int64_t q = lsi[lq] + (int64_t)qy * Wq + qx;          // query index == token index
-        const int64_t bqm = active ? (((int64_t)b * S + q) * M + m0 + head_in_slice) : 0;
+        const int64_t bqm = active ? (((int64_t)b * S + q) * M + head) : 0;
         const float *lp = loc + bqm * L * P * 2;
         const float *wp = aw + bqm * L * P;
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;   // this slice of token 0
@@ -161,19 +173,20 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
             ox = (2 * X0 + TW) * W / (2 * Wq) - WW / 2;
         };
         // issue this thread's share of a window copy into registers (loads stay in flight): its
-        // column, one row per step -- the row index and its bounds test are wave-uniform
-        float4 stage[WH];
+        // column, every ROWS_PER_PASS-th row
+        float4 stage[NSTAGE];
         auto fetch_window = [&](int l) {
             int oy, ox, H, W;
             origin(l, oy, ox, H, W);
             const int gx = ox + my_col;
-            const bool xok = col_ok && (unsigned)gx < (unsigned)W;
+            const bool xok = slot_ok && (unsigned)gx < (unsigned)W;
             const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
 #pragma unroll
-            for (int i = 0; i < WH; ++i) {
-                const int gy = oy + i;
+            for (int i = 0; i < NSTAGE; ++i) {
+                const int wy = my_row0 + i * Cfg::ROWS_PER_PASS;
+                const int gy = oy + wy;
                 stage[i] = make_float4(0, 0, 0, 0);
-                if (xok && (unsigned)gy < (unsigned)H)
+                if (xok && wy < WH && (unsigned)gy < (unsigned)H)
                     stage[i] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * W * row);
             }
         };
@@ -210,10 +223,11 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
                 int oy, ox, H, W;
                 origin(l, oy, ox, H, W);
                 __syncthreads();                          // everyone is done reading the old window
-                if (col_ok) {
+                if (slot_ok) {
 #pragma unroll
-                    for (int i = 0; i < WH; ++i)
-                        *reinterpret_cast<float4 *>(st_dst + i * WW * SLICE) = stage[i];
+                    for (int i = 0; i < NSTAGE; ++i)
+                        if (my_row0 + i * Cfg::ROWS_PER_PASS < WH)
+                            *reinterpret_cast<float4 *>(st_dst + i * Cfg::ROWS_PER_PASS * WW * SLICE) = stage[i];
                 }
                 // next level: window copy and sampling data go in flight under this level's taps
                 float4 na = la, nb = lb, nw = wa;
@@ -314,45 +328,61 @@ __global__ __launch_bounds__(Cfg::THREADS) void msda_fwd_tile(
     }
 }
 
-using Cfg16 = TileCfg<16, 8, 16, 6>;
-using Cfg32 = TileCfg<32, 8, 16, 6>;
+// 128-byte slices: 71.7 KB window, 2 workgroups / CU.  64-byte slices: 35.8 KB, 4 workgroups / CU (twice the
+// waves to hide LDS and global latency behind, at the price of duplicating the per-tap address math).
+using CfgWide16 = TileCfg<16, 32, 8, 16, 6>;
+using CfgWide32 = TileCfg<32, 32, 8, 16, 6>;
+using CfgNarrow16 = TileCfg<16, 16, 8, 16, 6>;
+using CfgNarrow32 = TileCfg<32, 16, 8, 16, 6>;
 
 bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16)
 {
     if (!aligned16 || P != TILE_P || L > TILE_MAX_LEVELS || Lq != S || B < 1) return false;
-    if (D == 16) return M % Cfg16::HPS == 0;
-    if (D == 32) return M % Cfg32::HPS == 0;
-    return false;
+    return (D == 16 && M % 2 == 0) || D == 32;
 }
 
-template <int D, typename Cfg>
+template <typename Cfg>
 static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *loc, const float *aw, int B, int S, int M, int L, float *out)
 {
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<D, Cfg>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_tile<D, Cfg>, Cfg::THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_tile<Cfg>, Cfg::THREADS,
                                                          Cfg::LDS_BYTES) != hipSuccess || per_cu < 1)
             per_cu = 2;
         int n = cus * per_cu;
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
     }();
-    hipLaunchKernelGGL((msda_fwd_tile<D, Cfg>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
+    hipLaunchKernelGGL((msda_fwd_tile<Cfg>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
                        st, value, shapes, lsi, loc, aw, B, S, M, L, out);
     return (int)hipGetLastError();
+}
+
+static bool narrow_slices()
+{
+    static const bool v = [] {
+        const char *e = getenv("MVDETR_MSDA_TILE_SLICE");      // tuning knob; measured: 128-byte slices win
+        return e && !strcmp(e, "64");
+    }();
+    return v;
 }
 
 int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
                       int P, float *out)
 {
-    if (D == 16) return launch_tile<16, Cfg16>(st, value, shapes, lsi, loc, aw, B, S, M, L, out);
-    if (D == 32) return launch_tile<32, Cfg32>(st, value, shapes, lsi, loc, aw, B, S, M, L, out);
+    const bool narrow = narrow_slices();
+    if (D == 16)
+        return narrow ? launch_tile<CfgNarrow16>(st, value, shapes, lsi, loc, aw, B, S, M, L, out)
+                      : launch_tile<CfgWide16>(st, value, shapes, lsi, loc, aw, B, S, M, L, out);
+    if (D == 32)
+        return narrow ? launch_tile<CfgNarrow32>(st, value, shapes, lsi, loc, aw, B, S, M, L, out)
+                      : launch_tile<CfgWide32>(st, value, shapes, lsi, loc, aw, B, S, M, L, out);
     return (int)hipErrorInvalidValue;
 }
 

@@ -110,3 +110,32 @@ def test_module_parity_of_parameters_and_init():
     assert float(m.value_proj.bias.abs().max()) == 0.0 and float(m.output_proj.bias.abs().max()) == 0.0
     with pytest.raises(ValueError):
         MSDeformAttn(130, 7, 8, 4)
+
+
+def test_dropin_aliases_reference_import_paths():
+    """Caller code written against the reference's package paths imports unchanged."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import mvdetr_amd.dropin\n"
+        "from multiview_detector.models.ops.modules import MSDeformAttn\n"
+        "from multiview_detector.models.ops.functions import MSDeformAttnFunction\n"
+        "from multiview_detector.models.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch\n"
+        "from multiview_detector.models.ops import warp_perspective\n"
+        "import MultiScaleDeformableAttention as MSDA\n"
+        "import mvdetr_amd.ops.modules as m\n"
+        "assert MSDeformAttn is m.MSDeformAttn and hasattr(MSDA, 'ms_deform_attn_forward')\n"
+        "print('DROPIN OK')\n"
+    ) % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "DROPIN OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_package_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under mvdetr_amd/ may reference it."""
+    import pathlib
+    for path in pathlib.Path(ROOT, "mvdetr_amd").rglob("*.py"):
+        text = path.read_text()
+        assert "import oracle" not in text and "from oracle" not in text, path
+    for path in pathlib.Path(ROOT, "mvdetr_amd", "csrc").glob("*"):
+        if path.suffix in (".hip", ".h"):
+            assert "oracle" not in path.read_text(), path
