@@ -6,7 +6,7 @@
 //
 // The reference picks among shared-memory reductions by block size because its block IS the D
 // channels of one (b,q,head) (16 threads at MVDeTr's D=16: a quarter of a wave64).  Here:
-//   msda_bwd_lanes<T, VEC, G>  G = D/VEC lanes (power of two <= 64) own one (b,q,head); the
+//   msda_bwd_lanes<T, VEC, G>  G = D/VEC lanes (power of two <= 64; VEC = 1 by default) own one (b,q,head); the
 //                              per-tap partial sums for grad_sampling_loc / grad_attn_weight are
 //                              reduced across those G lanes with DPP/xor shuffles inside the wave
 //                              -- no LDS, no barrier -- and lane 0 of the group stores them.
@@ -16,6 +16,8 @@
 // (cuh:125-152) -- is not deterministic.
 #include "common.h"
 #include "../../include/mvdetr_ops.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace mvdetr {
 
@@ -178,6 +180,24 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     constexpr int WIDE = 16 / (int)sizeof(T);
     const bool a16 = aligned(value, 16) && aligned(grad_col, 16);
+    // One channel per lane (G = D lanes per head): a wave's atomic instruction then covers whole
+    // 4*D-byte head segments, which the memory-side atomic units take as ONE request each, instead of four
+    // partial ones with 16-byte-per-lane vectors (measured at Wildtrack size: 3.15 ms vs 12.7 ms -- the
+    // kernel is bound by atomic requests, ~21 G/s, not by bytes).  MVDETR_MSDA_BWD_VEC=wide restores the
+    // vector mapping for comparison.
+    static const bool scalar_lanes = [] { const char *e = getenv("MVDETR_MSDA_BWD_VEC"); return !(e && !strcmp(e, "wide")); }();
+    if (scalar_lanes && D <= 64 && (D & (D - 1)) == 0) {
+        switch (D) {
+        case 1: return launch_lanes<T, 1, 1>(st, MSDA_BWD_ARGS);
+        case 2: return launch_lanes<T, 1, 2>(st, MSDA_BWD_ARGS);
+        case 4: return launch_lanes<T, 1, 4>(st, MSDA_BWD_ARGS);
+        case 8: return launch_lanes<T, 1, 8>(st, MSDA_BWD_ARGS);
+        case 16: return launch_lanes<T, 1, 16>(st, MSDA_BWD_ARGS);
+        case 32: return launch_lanes<T, 1, 32>(st, MSDA_BWD_ARGS);
+        case 64: return launch_lanes<T, 1, 64>(st, MSDA_BWD_ARGS);
+        default: break;
+        }
+    }
     if (a16 && D % WIDE == 0) {
         switch (D / WIDE) {
         case 1: return launch_lanes<T, WIDE, 1>(st, MSDA_BWD_ARGS);

@@ -24,43 +24,11 @@
 // (multiview_detector/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299).
 #include "common.h"
 #include "msda_dispatch.h"
+#include "msda_tile.h"
 #include <stdlib.h>
 #include <string.h>
 
 namespace mvdetr {
-
-constexpr int TILE_MAX_LEVELS = 16;     // 64-bit miss mask = L * P bits with P == 4
-constexpr int TILE_P = 4;
-
-template <int D_, int SLICE_, int TH_, int TW_, int R_> struct TileCfg {
-    static constexpr int D = D_, TH = TH_, TW = TW_, R = R_;
-    static constexpr int SLICE = SLICE_;              // floats of a token row staged per workgroup (32 = 128 B, 16 = 64 B)
-    static constexpr int SUBS = 2;                    // lanes per query, each owning half a slice
-    static constexpr int NV = SLICE / SUBS / 4;       // 16-byte chunks (float4 accumulators) per lane
-    static constexpr int PARTS = SLICE / 4;           // float4 per token in LDS
-    static constexpr int WH = TH + 2 * R, WW = TW + 2 * R;
-    static constexpr int THREADS = TH * TW * SUBS;
-    static constexpr int COLSLOTS = THREADS / PARTS;  // window columns a copy pass covers ...
-    static constexpr int ROWS_PER_PASS = COLSLOTS / WW;   // ... i.e. this many whole rows
-    static constexpr int NSTAGE = (WH + ROWS_PER_PASS - 1) / ROWS_PER_PASS;   // float4 per lane per window
-    static constexpr int LDS_BYTES = WH * WW * SLICE * 4;
-    static constexpr int TOK_PER_BANKROW = 256 / (SLICE * 4);                 // tokens per 256-byte LDS bank row
-    // workgroups per CU the LDS admits; the register allocation is capped to match (waves per SIMD)
-    static constexpr int WGS_PER_CU = (160 * 1024) / LDS_BYTES;
-    static constexpr int WAVES_PER_SIMD = WGS_PER_CU * (THREADS / 64) / 4;
-    static_assert(SLICE == 16 || SLICE == 32, "64- or 128-byte slices");
-    static_assert(D % (SLICE / SUBS) == 0, "a lane's channels must lie inside one head");
-    static_assert(ROWS_PER_PASS >= 1, "window copy: one pass must cover at least one row");
-};
-
-// Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
-// scalar registers).
-template <typename Cfg>
-__device__ __forceinline__ int tiles_of_level(const int64_t *shapes, int l)
-{
-    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    return ((H + Cfg::TH - 1) / Cfg::TH) * ((W + Cfg::TW - 1) / Cfg::TW);
-}
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
@@ -278,7 +246,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                             miss |= 1ull << (l * P + p);
                         }
                         // keep the taps apart: hoisting all 4 x 16 LDS reads together costs > 256 VGPRs
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (Cfg::TAP_FENCE) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 la = na;

@@ -1,0 +1,45 @@
+// Shared configuration of the LDS-tiled MSDA kernels (forward: msda_forward_tile.hip, backward:
+// msda_backward_tile.hip).  Internal, not part of the C ABI.
+#pragma once
+#include "common.h"
+
+namespace mvdetr {
+
+constexpr int TILE_MAX_LEVELS = 16;     // 64-bit miss mask = L * P bits with P == 4
+constexpr int TILE_P = 4;
+
+template <int D_, int SLICE_, int TH_, int TW_, int R_> struct TileCfg {
+    static constexpr int D = D_, TH = TH_, TW = TW_, R = R_;
+    static constexpr int SLICE = SLICE_;              // floats of a token row staged per workgroup (32 = 128 B, 16 = 64 B)
+    static constexpr int SUBS = 2;                    // lanes per query, each owning half a slice
+    static constexpr int NV = SLICE / SUBS / 4;       // 16-byte chunks (float4 accumulators) per lane
+    static constexpr int PARTS = SLICE / 4;           // float4 per token in LDS
+    static constexpr int WH = TH + 2 * R, WW = TW + 2 * R;
+    static constexpr int THREADS = TH * TW * SUBS;
+    static constexpr int COLSLOTS = THREADS / PARTS;  // window columns a copy pass covers ...
+    static constexpr int ROWS_PER_PASS = COLSLOTS / WW;   // ... i.e. this many whole rows
+    static constexpr int NSTAGE = (WH + ROWS_PER_PASS - 1) / ROWS_PER_PASS;   // float4 per lane per window
+    static constexpr int LDS_BYTES = WH * WW * SLICE * 4;
+    static constexpr int TOK_PER_BANKROW = 256 / (SLICE * 4);                 // tokens per 256-byte LDS bank row
+    // workgroups per CU the LDS admits; the register allocation is capped to match (waves per SIMD)
+    static constexpr int WGS_PER_CU = (160 * 1024) / LDS_BYTES;
+    static constexpr int WAVES_PER_SIMD = WGS_PER_CU * (THREADS / 64) / 4;
+#ifndef MVDETR_TAP_FENCE
+#define MVDETR_TAP_FENCE 1
+#endif
+    static constexpr bool TAP_FENCE = MVDETR_TAP_FENCE;
+    static_assert(SLICE == 16 || SLICE == 32, "64- or 128-byte slices");
+    static_assert(D % (SLICE / SUBS) == 0, "a lane's channels must lie inside one head");
+    static_assert(ROWS_PER_PASS >= 1, "window copy: one pass must cover at least one row");
+};
+
+// Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
+// scalar registers).
+template <typename Cfg>
+__device__ __forceinline__ int tiles_of_level(const int64_t *shapes, int l)
+{
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    return ((H + Cfg::TH - 1) / Cfg::TH) * ((W + Cfg::TW - 1) / Cfg::TW);
+}
+
+}  // namespace mvdetr

@@ -102,3 +102,4 @@ def set_forward_impl(name: str) -> str:
     """Tuning/testing knob: 'auto' | 'gather' | 'tile'.  Returns the previous setting."""
     prev = _lib.lib().mvdetr_msda_set_forward_impl(_IMPLS[name])
     return {v: k for k, v in _IMPLS.items()}[prev]
+

@@ -381,3 +381,73 @@ def test_auto_dispatch_rules(msda_impl):
               random_msda_inputs(1, [(4, 4)], 2, 16, 16, 3)):
         MSDA.ms_deform_attn_forward(*dev(*a), 64)
         assert MSDA.last_forward_impl() == "gather"
+
+
+# ---- backward at encoder shapes (partial tiles, misses, batch, NaN) vs the oracle ------------------------------------
+def _away_from_texel_centres(loc, shapes, eps=1e-4):
+    """1.0 where a tap's pixel coordinates are both > eps away from an integer.  The bilinear blend is
+    continuous there but its derivative w.r.t. the location is not (left and right slopes differ), so
+    grad_sampling_loc of a tap that lands within fp32 rounding of a texel centre legitimately depends on
+    which side the rounding falls; such taps (a handful per million) are excluded from grad_loc checks."""
+    wh = torch.stack([shapes[:, 1], shapes[:, 0]], -1).double()               # [L,2] (W,H)
+    px = loc.double() * wh[None, None, None, :, None, :] - 0.5
+    d = (px - px.round()).abs()
+    return (d.amin(-1) > eps).double()
+
+
+BWD_TILE_CASES = {
+    "mvdetr_like_partial_tiles": lambda: encoder_msda_inputs(7, 21, 43, seed=2, noise_px=1.0),
+    "wide_offsets_many_misses": lambda: encoder_msda_inputs(3, 24, 40, seed=4, noise_px=6.0),
+    "batch2": lambda: encoder_msda_inputs(4, 17, 19, B=2, seed=5),
+    "single_level": lambda: encoder_msda_inputs(1, 30, 50, seed=7),
+    "m2": lambda: encoder_msda_inputs(5, 12, 18, M=2, D=16, seed=8),
+    "uniform_locations": lambda: random_msda_inputs(1, [(20, 33)] * 3, 4, 16, 3 * 20 * 33, 4, seed=9, lo=-0.1, hi=1.1),
+}
+
+
+@pytest.mark.parametrize("case", sorted(BWD_TILE_CASES))
+def test_backward_encoder_shapes_vs_oracle(ops, case):
+    _, MSDA = ops
+    value, shapes, lsi, loc, aw = BWD_TILE_CASES[case]()
+    go = torch.randn(value.shape[0], loc.shape[1], value.shape[2] * value.shape[3],
+                     generator=torch.Generator().manual_seed(1))
+    ref = c_oracle.msda_backward(value.double(), shapes, lsi, loc.double(), aw.double(), go.double())
+    got = [x.cpu().double() for x in MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), 64)]
+    W = float(shapes[:, 1].max())
+    smooth = _away_from_texel_centres(loc, shapes)
+    for a, b, name, scale in zip(got, ref, ("grad_value", "grad_loc", "grad_aw"), (1.0, W, 1.0)):
+        assert a.shape == b.shape
+        err = (a - b).abs() / (scale + b.abs())
+        if name == "grad_loc":
+            err = err * smooth[..., None]
+        assert err.max().item() < 2e-4, name
+
+
+def test_backward_unequal_levels_and_nan(ops):
+    from helpers import pyramid_encoder_inputs
+    _, MSDA = ops
+    value, shapes, lsi, loc, aw = pyramid_encoder_inputs([(10, 37), (20, 11), (7, 7)], M=4, D=16, seed=10, noise_px=3.0)
+    loc[0, 5] = float("nan")
+    loc[0, 6] = 1e30
+    go = torch.randn(1, loc.shape[1], 64, generator=torch.Generator().manual_seed(2))
+    gv, gl, ga = [x.cpu() for x in MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), 64)]
+    assert torch.isfinite(gv).all() and float(gl[0, 5:7].abs().max()) == 0.0 and float(ga[0, 5:7].abs().max()) == 0.0
+    keep = torch.ones(loc.shape[1], dtype=torch.bool)
+    keep[5:7] = False
+    lo, awc, goc = [x[:, keep].double().contiguous() for x in (loc, aw, go)]
+    rv, rl, ra = c_oracle.msda_backward(value.double(), shapes, lsi, lo, awc, goc)
+    assert ((gv.double() - rv).abs() / (1 + rv.abs())).max().item() < 2e-4
+    assert ((ga[:, keep].double() - ra).abs() / (1 + ra.abs())).max().item() < 2e-4
+
+
+def test_training_through_the_function_matches_oracle_autograd(ops):
+    F, MSDA = ops
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(3, 10, 18, M=4, D=16, seed=3)
+    leaves = [x.clone().cuda().requires_grad_(True) for x in (value, loc, aw)]
+    out = F.apply(leaves[0], shapes.cuda(), lsi.cuda(), leaves[1], leaves[2], 64)
+    go = torch.randn(out.shape, generator=torch.Generator().manual_seed(4))
+    got = torch.autograd.grad(out, leaves, go.cuda())
+    cl = [x.clone().double().requires_grad_(True) for x in (value, loc, aw)]
+    ref = torch.autograd.grad(torch_oracle.msda_core(cl[0], shapes, cl[1], cl[2]), cl, go.double())
+    for a, b, scale in zip(got, ref, (1.0, 18.0, 1.0)):
+        assert ((a.cpu().double() - b).abs() / (scale + b.abs())).max().item() < 2e-4
