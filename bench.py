@@ -57,21 +57,27 @@ def parse():
 
 
 class KernelTimer:
-    """HIP-event brackets around every MSDA forward launch on the launching (current) stream."""
+    """HIP-event brackets around every MSDA forward launch (plain or fused entry point) on the
+    launching (current) stream."""
+
+    NAMES = ("ms_deform_attn_forward", "ms_deform_attn_forward_fused")
 
     def __init__(self, MSDA):
-        self.MSDA, self.orig, self.events, self.enabled = MSDA, MSDA.ms_deform_attn_forward, [], False
-        MSDA.ms_deform_attn_forward = self
+        self.events, self.enabled = [], False
+        for name in self.NAMES:
+            setattr(MSDA, name, self._wrap(getattr(MSDA, name)))
 
-    def __call__(self, *a):
-        if not self.enabled:
-            return self.orig(*a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = self.orig(*a)
-        e1.record()
-        self.events.append((e0, e1))
-        return out
+    def _wrap(self, fn):
+        def timed(*a):
+            if not self.enabled:
+                return fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a)
+            e1.record()
+            self.events.append((e0, e1))
+            return out
+        return timed
 
     def average_us(self):
         if not self.events:
@@ -133,10 +139,7 @@ def main():
     from mvdetr_amd.model import build_model
 
     MSDA.set_forward_impl(a.msda_impl)
-    timer = KernelTimer(MSDA)
-    # the autograd function resolved the extension at import time: point it at the timed wrapper
-    from mvdetr_amd.ops.functions import ms_deform_attn_func as _f
-    _f.MSDA = MSDA
+    timer = KernelTimer(MSDA)      # callers look the functions up on the module at call time
 
     geom = geometry.GEOMETRIES[a.config]
     model = build_model(a.config, seed=0).to(dev).eval()

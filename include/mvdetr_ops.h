@@ -50,6 +50,25 @@ int mvdetr_msda_forward_f64(void *stream, const double *value, const int64_t *sp
                             const double *attn_weight, int batch, int spatial_size, int num_heads,
                             int channels, int num_levels, int num_query, int num_point, double *out);
 
+/* Fused forward for deformable-encoder calls: the arithmetic MSDeformAttn.forward wraps around the core
+ * (multiview_detector/models/ops/modules/ms_deform_attn.py:100-107) happens inside the kernel, so the
+ * sampling_locations / attention_weights tensors are never written or re-read:
+ *     loc = reference_points[:, :, None] + sampling_offsets / (W_l, H_l);  aw = softmax_{L*P}(attn_logits)
+ *   reference_points [*, num_query, num_levels, num_point, 2]; consecutive batch elements are
+ *                    `ref_batch_stride` floats apart (0 = one set shared by the whole batch)
+ *   sampling_offsets [batch, num_query, num_heads, num_levels, num_point, 2]  (the Linear's raw output)
+ *   attn_logits      [batch, num_query, num_heads, num_levels, num_point]     (the Linear's raw output)
+ * Only the shapes the LDS-tiled kernel takes are supported (fp32, channels 16 or 32, num_point 4,
+ * num_levels <= 16, num_query == spatial_size, 16-byte aligned pointers): mvdetr_msda_fused_supported()
+ * returns 1 for them, and the forward returns hipErrorNotSupported (801) otherwise. */
+int mvdetr_msda_fused_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                int num_query, int num_point);
+int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start_index, const float *reference_points,
+                                  int64_t ref_batch_stride, const float *sampling_offsets,
+                                  const float *attn_logits, int batch, int spatial_size, int num_heads,
+                                  int channels, int num_levels, int num_query, int num_point, float *out);
+
 /* ---- Multi-scale deformable attention, backward -----------------------------------------------
  * Replaces ms_deformable_col2im_cuda (ms_deform_im2col_cuda.cuh:956-1327) and its six kernel
  * variants (cuh:301-920, device helpers cuh:87-234).

@@ -21,6 +21,7 @@ _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
 _MSDA_BWD = [_vp] * 7 + [_i] * 7 + [_vp] * 3
 _WARP = [_vp] * 3 + [_i] * 7 + [_vp]
+_MSDA_FUSED = [_vp] * 5 + [ctypes.c_int64] + [_vp] * 2 + [_i] * 7 + [_vp]
 
 SIGNATURES = {
     "mvdetr_ops_abi_version": ([], _i),
@@ -28,6 +29,8 @@ SIGNATURES = {
     "mvdetr_msda_set_forward_impl": ([_i], _i),
     "mvdetr_msda_forward_f32": (_MSDA_FWD, _i),
     "mvdetr_msda_forward_f64": (_MSDA_FWD, _i),
+    "mvdetr_msda_fused_supported": ([_i] * 7, _i),
+    "mvdetr_msda_forward_fused_f32": (_MSDA_FUSED, _i),
     "mvdetr_msda_backward_f32": (_MSDA_BWD, _i),
     "mvdetr_msda_backward_f64": (_MSDA_BWD, _i),
     "mvdetr_warp_perspective_forward_f32": (_WARP, _i),

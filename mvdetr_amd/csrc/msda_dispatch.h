@@ -25,6 +25,11 @@ int msda_fwd_impl_knob();
 
 bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16);
 
+// fused variant: reference points + raw offsets + raw logits (see msda_forward_tile.hip)
+int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                            const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
+                            int B, int S, int M, int D, int L, float *out);
+
 template <typename T>
 inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *aw, const T *out, int B,
                                         int S, int M, int D, int L, int Lq, int P)

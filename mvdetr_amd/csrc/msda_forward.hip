@@ -161,6 +161,35 @@ int mvdetr_msda_set_forward_impl(int impl)
     return prev;
 }
 
+int mvdetr_msda_fused_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                int num_query, int num_point)
+{
+    return mvdetr::msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, true)
+               ? 1 : 0;
+}
+
+int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start_index, const float *reference_points,
+                                  int64_t ref_batch_stride, const float *sampling_offsets,
+                                  const float *attn_logits, int batch, int spatial_size, int num_heads,
+                                  int channels, int num_levels, int num_query, int num_point, float *out)
+{
+    using namespace mvdetr;
+    if (bad_dims(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
+        return (int)hipErrorInvalidValue;
+    if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !out)
+        return (int)hipErrorInvalidValue;
+    const bool a16 = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(reference_points) |
+                       reinterpret_cast<uintptr_t>(sampling_offsets) | reinterpret_cast<uintptr_t>(attn_logits) |
+                       reinterpret_cast<uintptr_t>(out)) % 16) == 0 && ref_batch_stride % 4 == 0;
+    if (!msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, a16))
+        return (int)hipErrorNotSupported;
+    g_last_impl = "tile_fused";
+    return msda_forward_tile_fused(reinterpret_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
+                                   reference_points, ref_batch_stride, sampling_offsets, attn_logits, batch,
+                                   spatial_size, num_heads, channels, num_levels, out);
+}
+
 int mvdetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                             const int64_t *level_start_index, const float *sampling_loc,
                             const float *attn_weight, int batch, int spatial_size, int num_heads,

@@ -47,11 +47,15 @@ __device__ __forceinline__ void fma4(float2v &lo, float2v &hi, float w, const fl
 // r = (qx >> 1) mod chunks-per-head: same-parity neighbours then cover all slots of their head.  r is a
 // per-lane constant, so accumulator j simply holds channels 4*(j^r) .. +3 for the whole kernel and only
 // the final store (and the rare global-memory taps) need to know.  The LDS image itself stays linear.
-template <typename Cfg>
+// FUSED: `loc` holds the raw sampling offsets (output of the module's sampling_offsets Linear, pixels of
+// the sampled level) and `aw` the raw attention logits; the kernel adds the reference points
+// (`ref` [.., Lq, L, P, 2], batch stride `ref_bstride`, 0 = shared) and takes the softmax over L*P itself --
+// the arithmetic of ms_deform_attn.py:100-107 -- so neither tensor is materialised.
+template <typename Cfg, bool FUSED>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
-    int B, int S, int M, int L, float *__restrict__ out)
+    const float *__restrict__ ref, int64_t ref_bstride, int B, int S, int M, int L, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
     constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
         const int64_t bqm = active ? (((int64_t)b * S + q) * M + head) : 0;
         const float *lp = loc + bqm * L * P * 2;
         const float *wp = aw + bqm * L * P;
+        const float *rp = FUSED ? ref + b * ref_bstride + (active ? q : 0) * L * P * 2 : nullptr;
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;   // this slice of token 0
 
         float2v acc[2 * NV];
@@ -163,18 +168,54 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
         // Sampling data of the first level doubles as the probe.  If fewer than a quarter of the
         // workgroup's lanes have most of that level's taps inside the window, staging would be
         // wasted: the tile is then done entirely by the direct path below (all bits set in `miss`).
-        float4 la = make_float4(0, 0, 0, 0), lb = la, wa = la;
-        if (active) {
-            la = *reinterpret_cast<const float4 *>(lp);
-            lb = *reinterpret_cast<const float4 *>(lp + 4);
-            wa = *reinterpret_cast<const float4 *>(wp);
+        // sampling data of one level: unfused = final (x,y) pairs and weights; fused = raw offsets, logits
+        // and the reference points, turned into locations / weights where they are used
+        float4 la = make_float4(0, 0, 0, 0), lb = la, wa = la, ra = la, rb = la;
+        auto load_level = [&](int l, float4 &a, float4 &b2, float4 &w, float4 &r0, float4 &r1) {
+            a = *reinterpret_cast<const float4 *>(lp + l * P * 2);
+            b2 = *reinterpret_cast<const float4 *>(lp + l * P * 2 + 4);
+            w = *reinterpret_cast<const float4 *>(wp + l * P);
+            if constexpr (FUSED) {
+                r0 = *reinterpret_cast<const float4 *>(rp + l * P * 2);
+                r1 = *reinterpret_cast<const float4 *>(rp + l * P * 2 + 4);
+            }
+        };
+        // softmax statistics over the L*P logits of this (query, head)
+        float smax = 0.f, sinv = 1.f;
+        if constexpr (FUSED) {
+            if (active) {
+                smax = -INFINITY;
+                for (int l = 0; l < L; ++l) {
+                    const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
+                    smax = fmaxf(smax, fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
+                }
+                float ssum = 0.f;
+                for (int l = 0; l < L; ++l) {
+                    const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
+                    ssum += __expf(w.x - smax) + __expf(w.y - smax) + __expf(w.z - smax) + __expf(w.w - smax);
+                }
+                sinv = 1.f / ssum;
+            }
         }
+        // raw -> (x, y) in [0,1] and weights, for level dimensions (W, H)
+        auto finish = [&](float4 &a, float4 &b2, float4 &w, const float4 &r0, const float4 &r1, float W, float H) {
+            if constexpr (FUSED) {
+                const float iw = 1.f / W, ih = 1.f / H;
+                a = make_float4(r0.x + a.x * iw, r0.y + a.y * ih, r0.z + a.z * iw, r0.w + a.w * ih);
+                b2 = make_float4(r1.x + b2.x * iw, r1.y + b2.y * ih, r1.z + b2.z * iw, r1.w + b2.w * ih);
+                w = make_float4(__expf(w.x - smax) * sinv, __expf(w.y - smax) * sinv, __expf(w.z - smax) * sinv,
+                                __expf(w.w - smax) * sinv);
+            }
+        };
+        if (active) load_level(0, la, lb, wa, ra, rb);
         int hits = 0;
         {
             int oy, ox, H, W;
             origin(0, oy, ox, H, W);
             const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
-            const float xs[4] = {la.x, la.z, lb.x, lb.z}, ys[4] = {la.y, la.w, lb.y, lb.w};
+            float4 pa = la, pb = lb, pw = wa;
+            finish(pa, pb, pw, ra, rb, (float)W, (float)H);
+            const float xs[4] = {pa.x, pa.z, pb.x, pb.z}, ys[4] = {pa.y, pa.w, pb.y, pb.w};
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const float x = xs[p] * (float)W - 0.5f, y = ys[p] * (float)H - 0.5f;
@@ -198,18 +239,15 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                             *reinterpret_cast<float4 *>(st_dst + i * Cfg::ROWS_PER_PASS * WW * SLICE) = stage[i];
                 }
                 // next level: window copy and sampling data go in flight under this level's taps
-                float4 na = la, nb = lb, nw = wa;
+                float4 na = la, nb = lb, nw = wa, nra = ra, nrb = rb;
                 if (l + 1 < L) {
                     fetch_window(l + 1);
-                    if (active) {
-                        na = *reinterpret_cast<const float4 *>(lp + (l + 1) * P * 2);
-                        nb = *reinterpret_cast<const float4 *>(lp + (l + 1) * P * 2 + 4);
-                        nw = *reinterpret_cast<const float4 *>(wp + (l + 1) * P);
-                    }
+                    if (active) load_level(l + 1, na, nb, nw, nra, nrb);
                 }
                 __syncthreads();
 
                 if (active) {
+                    finish(la, lb, wa, ra, rb, (float)W, (float)H);
                     const float lxs[4] = {la.x, la.z, lb.x, lb.z};
                     const float lys[4] = {la.y, la.w, lb.y, lb.w};
                     const float aws[4] = {wa.x, wa.y, wa.z, wa.w};
@@ -252,6 +290,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                 la = na;
                 lb = nb;
                 wa = nw;
+                ra = nra;
+                rb = nrb;
             }
         } else {
             miss = L * P >= 64 ? ~0ull : ((1ull << (L * P)) - 1);
@@ -264,9 +304,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                 miss &= miss - 1;
                 const int l = bit / P;
                 const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-                const float x = lp[bit * 2 + 0] * (float)W - 0.5f;
-                const float y = lp[bit * 2 + 1] * (float)H - 0.5f;
-                const float a = wp[bit];
+                float lx = lp[bit * 2 + 0], ly = lp[bit * 2 + 1], a = wp[bit];
+                if constexpr (FUSED) {
+                    lx = rp[bit * 2 + 0] + lx * (1.f / (float)W);
+                    ly = rp[bit * 2 + 1] + ly * (1.f / (float)H);
+                    a = __expf(a - smax) * sinv;
+                }
+                const float x = lx * (float)W - 0.5f;
+                const float y = ly * (float)H - 0.5f;
                 if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
                 const Footprint<float> f = footprint(y, x, H, W);
                 const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * W + f.x0) * row;
@@ -309,25 +354,26 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
     return (D == 16 && M % 2 == 0) || D == 32;
 }
 
-template <typename Cfg>
+template <typename Cfg, bool FUSED>
 static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
-                       const float *loc, const float *aw, int B, int S, int M, int L, float *out)
+                       const float *loc, const float *aw, const float *ref, int64_t ref_bstride, int B, int S,
+                       int M, int L, float *out)
 {
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_tile<Cfg>, Cfg::THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_tile<Cfg, FUSED>, Cfg::THREADS,
                                                          Cfg::LDS_BYTES) != hipSuccess || per_cu < 1)
             per_cu = 2;
         int n = cus * per_cu;
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
     }();
-    hipLaunchKernelGGL((msda_fwd_tile<Cfg>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
-                       st, value, shapes, lsi, loc, aw, B, S, M, L, out);
+    hipLaunchKernelGGL((msda_fwd_tile<Cfg, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
+                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out);
     return (int)hipGetLastError();
 }
 
@@ -340,18 +386,33 @@ static bool narrow_slices()
     return v;
 }
 
+template <bool FUSED>
+static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *loc, const float *aw, const float *ref, int64_t ref_bstride, int B, int S,
+                         int M, int D, int L, float *out)
+{
+    const bool narrow = narrow_slices();
+    if (D == 16)
+        return narrow ? launch_tile<CfgNarrow16, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out)
+                      : launch_tile<CfgWide16, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out);
+    if (D == 32)
+        return narrow ? launch_tile<CfgNarrow32, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out)
+                      : launch_tile<CfgWide32, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out);
+    return (int)hipErrorInvalidValue;
+}
+
 int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
                       int P, float *out)
 {
-    const bool narrow = narrow_slices();
-    if (D == 16)
-        return narrow ? launch_tile<CfgNarrow16>(st, value, shapes, lsi, loc, aw, B, S, M, L, out)
-                      : launch_tile<CfgWide16>(st, value, shapes, lsi, loc, aw, B, S, M, L, out);
-    if (D == 32)
-        return narrow ? launch_tile<CfgNarrow32>(st, value, shapes, lsi, loc, aw, B, S, M, L, out)
-                      : launch_tile<CfgWide32>(st, value, shapes, lsi, loc, aw, B, S, M, L, out);
-    return (int)hipErrorInvalidValue;
+    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, B, S, M, D, L, out);
+}
+
+int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                            const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
+                            int B, int S, int M, int D, int L, float *out)
+{
+    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, B, S, M, D, L, out);
 }
 
 }  // namespace mvdetr

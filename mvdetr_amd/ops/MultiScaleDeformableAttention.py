@@ -90,6 +90,40 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [grad_value, grad_loc, grad_aw]
 
 
+def fused_supported(value, num_levels, num_query, num_point) -> bool:
+    """True when ms_deform_attn_forward_fused takes this call (deformable-encoder shapes, fp32)."""
+    if not value.is_cuda or value.dtype != torch.float32:
+        return False
+    B, S, M, D = value.shape
+    return bool(_lib.lib().mvdetr_msda_fused_supported(B, S, M, D, num_levels, num_query, num_point))
+
+
+def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
+                                 attn_logits):
+    """Core + the module arithmetic around it (ms_deform_attn.py:100-107) in one kernel (inference):
+    value [B,S,M,D]; reference_points [B or 1, Lq, L, P, 2] (may be a batch-expanded view);
+    sampling_offsets [B,Lq,M,L,P,2] and attn_logits [B,Lq,M,L,P] are the raw Linear outputs.
+    -> [B, Lq, M*D].  No extension counterpart in the reference: this is SURVEY row f1."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)])
+    B, S, M, D = value.shape
+    L, Lq, P = spatial_shapes.shape[0], sampling_offsets.shape[1], sampling_offsets.shape[4]
+    if reference_points.shape[-4:] != (Lq, L, P, 2) or not reference_points.is_cuda:
+        raise RuntimeError("reference_points must be a CUDA tensor of shape [B or 1, Lq, L, P, 2]")
+    if not reference_points[0].is_contiguous():
+        reference_points = reference_points.contiguous()
+    rstride = reference_points.stride(0) if reference_points.shape[0] > 1 else 0
+    _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().mvdetr_msda_forward_fused_f32(
+            _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), reference_points.data_ptr(), rstride, sampling_offsets.data_ptr(),
+            attn_logits.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr())
+    _lib.check(rc, "ms_deform_attn_forward_fused")
+    return out
+
+
 def last_forward_impl() -> str:
     """Which kernel variant the last forward on this thread dispatched to (bench/tests only)."""
     return _lib.lib().mvdetr_msda_last_forward_impl().decode()

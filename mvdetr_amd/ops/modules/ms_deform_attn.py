@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import MultiScaleDeformableAttention as MSDA
 from ..functions import MSDeformAttnFunction
 
 
@@ -41,6 +42,8 @@ class MSDeformAttn(nn.Module):
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
         self._validated = None
+        # inference calls of deformable-encoder shape run softmax + location arithmetic inside the kernel
+        self.fused_inference = True
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -85,6 +88,13 @@ class MSDeformAttn(nn.Module):
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
         offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        if (self.fused_inference and reference_points.shape[-1] == 2 and reference_points.dim() == 5
+                and not (torch.is_grad_enabled() and (value.requires_grad or offsets.requires_grad))
+                and MSDA.fused_supported(value, self.n_levels, Len_q, self.n_points)):
+            out = MSDA.ms_deform_attn_forward_fused(
+                value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,
+                offsets.contiguous(), weights.view(N, Len_q, self.n_heads, self.n_levels, self.n_points).contiguous())
+            return self.output_proj(out)
         weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)

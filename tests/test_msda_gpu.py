@@ -451,3 +451,67 @@ def test_training_through_the_function_matches_oracle_autograd(ops):
     ref = torch.autograd.grad(torch_oracle.msda_core(cl[0], shapes, cl[1], cl[2]), cl, go.double())
     for a, b, scale in zip(got, ref, (1.0, 18.0, 1.0)):
         assert ((a.cpu().double() - b).abs() / (scale + b.abs())).max().item() < 2e-4
+
+
+# ---- fused inference path (softmax + sampling locations inside the kernel) --------------------------------
+def _module_with_random_projections(d_model, L, M, P, seed):
+    from mvdetr_amd.ops.modules import MSDeformAttn
+    torch.manual_seed(seed)
+    mod = MSDeformAttn(d_model, L, M, P)
+    with torch.no_grad():
+        mod.sampling_offsets.weight.normal_(0, 0.05)
+        mod.attention_weights.weight.normal_(0, 0.3)
+        mod.attention_weights.bias.normal_(0, 0.5)
+    return mod
+
+
+@pytest.mark.parametrize("L,H,W,B,d_model", [(7, 21, 43, 1, 128), (3, 16, 24, 2, 128), (16, 9, 17, 1, 256), (4, 40, 64, 1, 128)])
+def test_fused_module_forward_vs_oracle_and_unfused(ops, L, H, W, B, d_model):
+    _, MSDA = ops
+    M, P = 8, 4
+    mod = _module_with_random_projections(d_model, L, M, P, seed=L).cuda().eval()
+    shapes = torch.tensor([[H, W]] * L)
+    S = L * H * W
+    g = torch.Generator().manual_seed(L + H)
+    query = torch.randn(B, S, d_model, generator=g)
+    src = torch.randn(B, S, d_model, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)      # [S,L,P,2]
+    ref = ref + 0.002 * torch.randn(ref.shape, generator=g)
+    ref_b = ref.unsqueeze(0).expand(B, -1, -1, -1, -1)                                   # stride-0 batch
+    with torch.no_grad():
+        fused = mod(query.cuda(), ref_b.cuda(), src.cuda(), shapes.cuda(), level_start_index(shapes).cuda())
+        assert MSDA.last_forward_impl() == "tile_fused"
+        mod.fused_inference = False
+        unfused = mod(query.cuda(), ref_b.cuda(), src.cuda(), shapes.cuda(), level_start_index(shapes).cuda())
+        assert MSDA.last_forward_impl() == "tile"
+    params = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+    want = torch_oracle.msda_module(params, query, ref_b, src, shapes, M, P)
+    assert (fused.cpu() - want).abs().max().item() < FP32_TOL
+    assert (unfused.cpu() - want).abs().max().item() < FP32_TOL
+    assert (fused - unfused).abs().max().item() < 2e-5
+    # per-batch (non-expanded) reference points take the same path
+    ref2 = ref_b.contiguous().cuda()
+    mod.fused_inference = True
+    with torch.no_grad():
+        again = mod(query.cuda(), ref2, src.cuda(), shapes.cuda(), level_start_index(shapes).cuda())
+    assert torch.equal(again, fused)
+
+
+def test_fused_path_is_inference_only_and_training_still_matches(ops):
+    _, MSDA = ops
+    L, H, W, M, P, d_model = 3, 10, 18, 8, 4, 128
+    mod = _module_with_random_projections(d_model, L, M, P, seed=1).cuda().train()
+    shapes = torch.tensor([[H, W]] * L).cuda()
+    S = L * H * W
+    query = torch.randn(1, S, d_model, device="cuda", requires_grad=True)
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)[None].cuda()
+    out = mod(query, ref, query, shapes, level_start_index(shapes))
+    assert MSDA.last_forward_impl() == "tile"                      # grad mode: the differentiable path
+    out.square().mean().backward()
+    assert query.grad is not None and mod.sampling_offsets.weight.grad.abs().sum() > 0
+    with torch.no_grad():
+        out2 = mod(query, ref, query, shapes, level_start_index(shapes))
+    assert MSDA.last_forward_impl() == "tile_fused"
+    assert (out2 - out.detach()).abs().max().item() < 2e-5
