@@ -180,31 +180,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                 r1 = *reinterpret_cast<const float4 *>(rp + l * P * 2 + 4);
             }
         };
-        // softmax statistics over the L*P logits of this (query, head)
-        float smax = 0.f, sinv = 1.f;
-        if constexpr (FUSED) {
-            if (active) {
-                smax = -INFINITY;
-                for (int l = 0; l < L; ++l) {
-                    const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
-                    smax = fmaxf(smax, fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
-                }
-                float ssum = 0.f;
-                for (int l = 0; l < L; ++l) {
-                    const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
-                    ssum += __expf(w.x - smax) + __expf(w.y - smax) + __expf(w.z - smax) + __expf(w.w - smax);
-                }
-                sinv = 1.f / ssum;
-            }
-        }
-        // raw -> (x, y) in [0,1] and weights, for level dimensions (W, H)
-        auto finish = [&](float4 &a, float4 &b2, float4 &w, const float4 &r0, const float4 &r1, float W, float H) {
+        // FUSED: online softmax over the L*P logits of this (query, head) -- running maximum `smax` and
+        // running sum `ssum` of exp(logit - smax); the accumulators are rescaled when the maximum moves and
+        // divided by the final sum at the end, so the logits are read exactly once, level by level.
+        float smax = -INFINITY, ssum = 0.f;
+        // raw -> (x, y) in [0,1] for level dimensions (W, H); logits are left raw here
+        auto finish = [&](float4 &a, float4 &b2, const float4 &r0, const float4 &r1, float W, float H) {
             if constexpr (FUSED) {
                 const float iw = 1.f / W, ih = 1.f / H;
                 a = make_float4(r0.x + a.x * iw, r0.y + a.y * ih, r0.z + a.z * iw, r0.w + a.w * ih);
                 b2 = make_float4(r1.x + b2.x * iw, r1.y + b2.y * ih, r1.z + b2.z * iw, r1.w + b2.w * ih);
-                w = make_float4(__expf(w.x - smax) * sinv, __expf(w.y - smax) * sinv, __expf(w.z - smax) * sinv,
-                                __expf(w.w - smax) * sinv);
             }
         };
         if (active) load_level(0, la, lb, wa, ra, rb);
@@ -213,8 +198,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
             int oy, ox, H, W;
             origin(0, oy, ox, H, W);
             const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
-            float4 pa = la, pb = lb, pw = wa;
-            finish(pa, pb, pw, ra, rb, (float)W, (float)H);
+            float4 pa = la, pb = lb;
+            finish(pa, pb, ra, rb, (float)W, (float)H);
             const float xs[4] = {pa.x, pa.z, pb.x, pb.z}, ys[4] = {pa.y, pa.w, pb.y, pb.w};
 #pragma unroll
             for (int p = 0; p < P; ++p) {
@@ -247,7 +232,18 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                 __syncthreads();
 
                 if (active) {
-                    finish(la, lb, wa, ra, rb, (float)W, (float)H);
+                    finish(la, lb, ra, rb, (float)W, (float)H);
+                    if constexpr (FUSED) {
+                        // fold this level's logits into the running softmax; rescale what was accumulated
+                        const float m = fmaxf(smax, fmaxf(fmaxf(wa.x, wa.y), fmaxf(wa.z, wa.w)));
+                        const float sc = __expf(smax - m);               // exp(-inf) = 0 on the first level
+                        wa = make_float4(__expf(wa.x - m), __expf(wa.y - m), __expf(wa.z - m), __expf(wa.w - m));
+                        ssum = ssum * sc + (wa.x + wa.y) + (wa.z + wa.w);
+                        smax = m;
+                        const float2v scv = {sc, sc};
+#pragma unroll
+                        for (int i = 0; i < 2 * NV; ++i) acc[i] *= scv;
+                    }
                     const float lxs[4] = {la.x, la.z, lb.x, lb.z};
                     const float lys[4] = {la.y, la.w, lb.y, lb.w};
                     const float aws[4] = {wa.x, wa.y, wa.z, wa.w};
@@ -295,6 +291,18 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
             }
         } else {
             miss = L * P >= 64 ? ~0ull : ((1ull << (L * P)) - 1);
+            if constexpr (FUSED) {
+                if (active) {                             // plain two-pass statistics for the direct path
+                    for (int l = 0; l < L; ++l) {
+                        const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
+                        smax = fmaxf(smax, fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
+                    }
+                    for (int l = 0; l < L; ++l) {
+                        const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
+                        ssum += __expf(w.x - smax) + __expf(w.y - smax) + __expf(w.z - smax) + __expf(w.w - smax);
+                    }
+                }
+            }
         }
 
         if (active) {
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                 if constexpr (FUSED) {
                     lx = rp[bit * 2 + 0] + lx * (1.f / (float)W);
                     ly = rp[bit * 2 + 1] + ly * (1.f / (float)H);
-                    a = __expf(a - smax) * sinv;
+                    a = __expf(a - smax);                  // un-normalised, like the accumulators
                 }
                 const float x = lx * (float)W - 0.5f;
                 const float y = ly * (float)H - 0.5f;
@@ -331,6 +339,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                     fma4(acc[2 * k], acc[2 * k + 1], w10, c10);
                     fma4(acc[2 * k], acc[2 * k + 1], w11, c11);
                 }
+            }
+            if constexpr (FUSED) {
+                const float inv = 1.f / ssum;
+                const float2v invv = {inv, inv};
+#pragma unroll
+                for (int i = 0; i < 2 * NV; ++i) acc[i] *= invv;
             }
             float *o = out + bqm * D + ch_off;
 #pragma unroll
