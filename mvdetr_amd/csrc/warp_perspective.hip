@@ -11,10 +11,10 @@
 // tensor dtype, and pixels whose footprint misses the source image are stored as zeros without
 // touching `src`.
 //
-// Work mapping (wave64): a block is 64 consecutive destination pixels (lanes = pixels, so both the
-// source gathers and the NCHW stores are coalesced along x) times a group of up to 64 channels
-// split over the block's 4 waves.  For the channel-last output the 64x64 tile is transposed
-// through LDS (65-float rows, conflict-free both ways) so the stores are 256-byte rows.
+// Work mapping (wave64): a block is an 8x8 tile of destination pixels (lanes = pixels; its pre-image is a
+// compact source patch, so a load instruction touches a handful of cache lines) times a group of up to 64
+// channels split over the block's 4 waves.  For the channel-last output the 64x64 (pixel, channel) tile is
+// transposed through LDS (65-float rows, conflict-free both ways) so the stores are 256-byte rows.
 #include "common.h"
 #include "../../include/mvdetr_ops.h"
 
@@ -95,16 +95,35 @@ __device__ __forceinline__ void load_pair(const T *p, bool v0, bool v1, T &a, T 
     b = v1 ? p[1] : T(0);
 }
 
-// Linear block id -> (pixel tile, channel group).  Consecutive blocks are dealt round-robin to the 8
-// XCDs by the dispatcher; that also balances the very uneven per-view work (out-of-view tiles cost almost
-// nothing), which a contiguous band per XCD does not (measured: 100 us round-robin vs 135 us banded).
-__device__ __forceinline__ bool warp_block(int64_t tiles, int groups, int64_t &tile, int &group)
+// Block id -> (view, 8x8 destination tile, channel group).  The world grid is not aligned with the image
+// axes (a ground-plane row is a slanted, perspective-foreshortened line in the camera image), so 64
+// consecutive pixels of one destination ROW gather from ~30 different source cache lines per load
+// instruction (measured: 66 M L1 accesses per launch, i.e. the kernel ran at the texture-address rate, and
+// neither fewer bytes nor a different XCD assignment changed its 100 us).  An 8x8 destination tile maps to
+// a compact source patch instead: a handful of lines per load.
+constexpr int WARP_TW = 8, WARP_TH = 8;
+static_assert(WARP_TW * WARP_TH == WARP_PIX, "one lane per tile pixel");
+
+struct WarpBlock {
+    int n, i0, j0, group;
+};
+
+__device__ __forceinline__ bool warp_block(int N, int H, int W, int groups, WarpBlock &wb)
 {
-    const int64_t total = tiles * groups, logical = blockIdx.x;
-    if (logical >= total) return false;
-    tile = logical / groups;
-    group = (int)(logical % groups);
-    return true;
+    const int tx = (W + WARP_TW - 1) / WARP_TW, ty = (H + WARP_TH - 1) / WARP_TH;
+    int r = blockIdx.x;
+    wb.group = r % groups;
+    r /= groups;
+    wb.j0 = (r % tx) * WARP_TW;
+    r /= tx;
+    wb.i0 = (r % ty) * WARP_TH;
+    wb.n = r / ty;
+    return wb.n < N;
+}
+
+inline int64_t warp_grid(int N, int H, int W, int groups)
+{
+    return (int64_t)N * ((H + WARP_TH - 1) / WARP_TH) * ((W + WARP_TW - 1) / WARP_TW) * groups;
 }
 
 template <typename T, bool NHWC>
@@ -115,22 +134,16 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
     __shared__ float tile[NHWC && sizeof(T) == 4 ? WARP_PIX * (WARP_CH + 1) : 1];
     const int lane = threadIdx.x & (WARP_PIX - 1);
     const int sub = threadIdx.x / WARP_PIX;
-    const int64_t npix = (int64_t)N * H * W;
-    int64_t ptile;
-    int cgroup;
-    if (!warp_block((npix + WARP_PIX - 1) / WARP_PIX, (C + WARP_CH - 1) / WARP_CH, ptile, cgroup)) return;
-    const int64_t pix = ptile * WARP_PIX + lane;
-    const int cbase = cgroup * WARP_CH;
+    WarpBlock wb;
+    if (!warp_block(N, H, W, (C + WARP_CH - 1) / WARP_CH, wb)) return;
+    const int n = wb.n, i = wb.i0 + lane / WARP_TW, j = wb.j0 + lane % WARP_TW;
+    const int64_t pix = ((int64_t)n * H + i) * W + j;
+    const int cbase = wb.group * WARP_CH;
     constexpr int CPT = WARP_CH / WARP_SUB;
-    const bool live = pix < npix;
-    int n = 0, i = 0, j = 0;
+    const bool live = i < H && j < W;
     SrcCoord sc;
     sc.any = false;
     if (live) {
-        n = (int)(pix / ((int64_t)H * W));
-        const int rem = (int)(pix - (int64_t)n * H * W);
-        i = rem / W;
-        j = rem - i * W;
         double x, y;
         source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
         sc = make_coord(x, y, h, w);
@@ -161,13 +174,13 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
     if constexpr (NHWC && sizeof(T) == 4) {
         __syncthreads();
         // 64 pixels x 64 channels -> rows of 64 consecutive channels per pixel
-        const int64_t pix0 = ptile * WARP_PIX;
         const int ch = threadIdx.x & (WARP_CH - 1);
 #pragma unroll 4
         for (int k = 0; k < WARP_PIX / WARP_SUB; ++k) {
             const int p = k * WARP_SUB + sub;
-            if (pix0 + p < npix && cbase + ch < C)
-                dst[(pix0 + p) * C + cbase + ch] = (T)tile[p * (WARP_CH + 1) + ch];
+            const int pi = wb.i0 + p / WARP_TW, pj = wb.j0 + p % WARP_TW;
+            if (pi < H && pj < W && cbase + ch < C)
+                dst[(((int64_t)n * H + pi) * W + pj) * C + cbase + ch] = (T)tile[p * (WARP_CH + 1) + ch];
         }
     }
 }
@@ -179,17 +192,13 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_bwd(
 {
     const int lane = threadIdx.x & (WARP_PIX - 1);
     const int sub = threadIdx.x / WARP_PIX;
-    const int64_t npix = (int64_t)N * H * W;
-    int64_t ptile;
-    int cgroup;
-    if (!warp_block((npix + WARP_PIX - 1) / WARP_PIX, (C + WARP_CH - 1) / WARP_CH, ptile, cgroup)) return;
-    const int64_t pix = ptile * WARP_PIX + lane;
-    if (pix >= npix) return;
-    const int cbase = cgroup * WARP_CH;
+    WarpBlock wb;
+    if (!warp_block(N, H, W, (C + WARP_CH - 1) / WARP_CH, wb)) return;
+    const int n = wb.n, i = wb.i0 + lane / WARP_TW, j = wb.j0 + lane % WARP_TW;
+    if (i >= H || j >= W) return;
+    const int64_t pix = ((int64_t)n * H + i) * W + j;
+    const int cbase = wb.group * WARP_CH;
     constexpr int CPT = WARP_CH / WARP_SUB;
-    const int n = (int)(pix / ((int64_t)H * W));
-    const int rem = (int)(pix - (int64_t)n * H * W);
-    const int i = rem / W, j = rem - i * W;
     double x, y;
     source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
     const SrcCoord sc = make_coord(x, y, h, w);
@@ -218,9 +227,8 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
     const int64_t npix = (int64_t)N * H * W;
     if (npix == 0 || C == 0) return 0;
     if (!a || !Mv || !o) return (int)hipErrorInvalidValue;
-    const int64_t tiles = (npix + WARP_PIX - 1) / WARP_PIX;
     const int groups = (C + WARP_CH - 1) / WARP_CH;
-    const int64_t blocks = tiles * groups;
+    const int64_t blocks = warp_grid(N, H, W, groups);
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)blocks), block(WARP_PIX * WARP_SUB);
