@@ -36,6 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # synthetic-input builders shared with the parity tests
 
 import torch  # noqa: E402
 
@@ -118,9 +119,32 @@ def cpu_baseline(model, imgs_cpu, proj_cpu, budget_s):
         while len(times) < 5 and sum(times) + first <= budget_s:
             times.append(one())
     frames, t_total = len(times), sum(times)
-    return {"value": round(frames / t_total, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{frames} full frame(s) ({model.num_cam} views 3x{imgs_cpu.shape[-2]}x{imgs_cpu.shape[-1]} -> BEV), "
-                      f"oracle/frame_oracle.py on {torch.get_num_threads()} host threads, {t_total:.1f} s"}
+    res = {"value": round(frames / t_total, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{frames} full frame(s) ({model.num_cam} views 3x{imgs_cpu.shape[-2]}x{imgs_cpu.shape[-1]} -> BEV), "
+                     f"oracle/frame_oracle.py on {torch.get_num_threads()} host threads, {t_total:.1f} s"}
+    # the two hot ops alone (the reference's CPU formulation), all cores and -- because the reference pins
+    # OMP_NUM_THREADS=1 (main.py:3) -- one thread; one call each, a few seconds in total
+    from helpers import encoder_msda_inputs
+    from oracle import torch_oracle
+    wf = model.world_feat
+    h, w = (int(x) for x in wf.spatial_shapes[0])
+    value, shapes, _, loc, aw = encoder_msda_inputs(model.num_cam, h, w, 8, wf.hidden_dim // 8, 4, seed=0)
+    feat = torch.randn(model.num_cam, wf.hidden_dim, *model.Rimg_shape)
+    ops = {}
+    with torch.no_grad():
+        torch_oracle.msda_core(value, shapes, loc, aw)          # warm-up (allocator, thread pool)
+    for tag, nthreads in (("all_cores", cores), ("1_thread", 1)):
+        torch.set_num_threads(nthreads)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            torch_oracle.msda_core(value, shapes, loc, aw)
+            t1 = time.perf_counter()
+            torch_oracle.warp_perspective(feat, proj_cpu, model.Rworld_shape)
+            t2 = time.perf_counter()
+        ops[tag] = {"threads": nthreads, "msda_core_s": round(t1 - t0, 3), "warp_s": round(t2 - t1, 3)}
+    torch.set_num_threads(cores)
+    res["ops"] = ops
+    return res
 
 
 def main():
