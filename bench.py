@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="wildtrack", choices=["wildtrack", "multiviewx", "stress16"])
     ap.add_argument("--parallel", default="dp", choices=["dp", "views"])
+    ap.add_argument("--batch", type=int, default=1, help="frames per step per rank (dp mode; the reference only supports 1)")
     ap.add_argument("--augment", action="store_true", help="random affine augmentation matrices instead of identity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -169,7 +170,8 @@ def main():
     model = build_model(a.config, seed=0).to(dev).eval()
     N, (Hi, Wi) = geom.num_cam, geom.input_img_shape
     g = torch.Generator().manual_seed(1000 + rank)
-    M = geometry.random_affine_mats(1, N, (Hi, Wi), seed=rank) if a.augment else torch.eye(3).repeat(1, N, 1, 1)
+    Bf = a.batch if not (a.parallel == "views" and world > 1) else 1
+    M = geometry.random_affine_mats(Bf, N, (Hi, Wi), seed=rank) if a.augment else torch.eye(3).repeat(Bf, N, 1, 1)
 
     if a.parallel == "views" and world > 1:
         runner = mdist.ViewShardedFrame(model)
@@ -179,11 +181,11 @@ def main():
         step = lambda: runner(imgs, M)                       # noqa: E731
         frames_per_step, scaling = 1, "strong"
     else:
-        imgs = torch.randn(1, N, 3, Hi, Wi, generator=g).to(dev)
+        imgs = torch.randn(Bf, N, 3, Hi, Wi, generator=g).to(dev)
         def step():
             with torch.no_grad():
                 return model(imgs, M)
-        frames_per_step, scaling = world, "weak"
+        frames_per_step, scaling = world * Bf, "weak"
 
     for _ in range(a.warmup):
         step()
@@ -215,15 +217,15 @@ def main():
             for _ in range(a.steps):
                 model.hot_path(feat, proj)
             torch.cuda.synchronize()
-            hot_ms = (time.perf_counter() - t1) / a.steps * 1e3
+            hot_ms = (time.perf_counter() - t1) / a.steps * 1e3 / Bf
 
     if rank != 0:
         return
     wf = model.world_feat
     S = int(wf.spatial_shapes.prod(1).sum())
     L, Mh, D, P = N, 8, wf.hidden_dim // 8, 4
-    alg_bytes = 4 * (S * Mh * D + 3 * S * Mh * L * P + S * Mh * D)
-    traffic, traffic_src = load_traffic()
+    alg_bytes = 4 * Bf * (S * Mh * D + 3 * S * Mh * L * P + S * Mh * D)
+    traffic, traffic_src = load_traffic() if (a.config == "wildtrack" and Bf == 1) else (None, None)
     achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us else None
     res = {
         "metric": "multiview frames/s (7-cam Wildtrack) + MSDeformAttn HBM GB/s vs roofline",
@@ -234,7 +236,8 @@ def main():
         "config": {"workload": f"{a.config} {N}-cam frame, --world_feat deform_trans, ResNet18 trunk: "
                                f"{N}x3x{Hi}x{Wi} -> {geom.feat_channels}-ch world feat {geom.Rworld_shape[0]}x{geom.Rworld_shape[1]} "
                                f"-> BEV (BASELINE.json configs[1])" if a.config == "wildtrack" else f"{a.config} {N}-cam frame",
-                   "frames_per_step": frames_per_step, "parallelism": f"{a.parallel}{world}", "augment": bool(a.augment),
+                   "frames_per_step": frames_per_step, "batch_per_rank": Bf, "parallelism": f"{a.parallel}{world}",
+                   "augment": bool(a.augment),
                    "weights": "seeded random"},
         "roofline": {"bound": "hbm", "kernel": f"msda_forward[{impl}]", "achieved": round(achieved, 1) if achieved else None,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4) if achieved else None,
@@ -245,7 +248,7 @@ def main():
                      "what": "warp_perspective + DeformTransWorldFeat (3 x MSDeformAttn), features resident"},
     }
     if world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(model, imgs.cpu(), model.frame_proj_mats(M), a.cpu_budget_s)
+        res["cpu_baseline"] = cpu_baseline(model, imgs[:1].cpu(), model.frame_proj_mats(M[:1]), a.cpu_budget_s)
     else:
         res["cpu_baseline"] = None
     print(json.dumps(res), flush=True)
