@@ -70,12 +70,12 @@ class KernelTimer:
             setattr(MSDA, name, self._wrap(getattr(MSDA, name)))
 
     def _wrap(self, fn):
-        def timed(*a):
+        def timed(*a, **kw):
             if not self.enabled:
-                return fn(*a)
+                return fn(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = fn(*a)
+            out = fn(*a, **kw)
             e1.record()
             self.events.append((e0, e1))
             return out

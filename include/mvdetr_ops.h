@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 1
+#define MVDETR_OPS_ABI_VERSION 2
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -58,6 +58,11 @@ int mvdetr_msda_forward_f64(void *stream, const double *value, const int64_t *sp
  *                    `ref_batch_stride` floats apart (0 = one set shared by the whole batch)
  *   sampling_offsets [batch, num_query, num_heads, num_levels, num_point, 2]  (the Linear's raw output)
  *   attn_logits      [batch, num_query, num_heads, num_levels, num_point]     (the Linear's raw output)
+ *   level_major != 0: the two raw tensors are [batch, num_query, num_levels, num_heads, num_point(, 2)]
+ *                    instead -- the caller permutes the Linear's weight rows once; keeps what one level
+ *                    iteration reads in the same cache lines
+ *   offsets_query_stride / logits_query_stride: floats from one query's block to the next (0 = dense), so
+ *                    both may be column blocks of one wider GEMM output; multiples of 4
  * Only the shapes the LDS-tiled kernel takes are supported (fp32, channels 16 or 32, num_point 4,
  * num_levels <= 16, num_query == spatial_size, 16-byte aligned pointers): mvdetr_msda_fused_supported()
  * returns 1 for them, and the forward returns hipErrorNotSupported (801) otherwise. */
@@ -66,7 +71,8 @@ int mvdetr_msda_fused_supported(int batch, int spatial_size, int num_heads, int 
 int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                                   const int64_t *level_start_index, const float *reference_points,
                                   int64_t ref_batch_stride, const float *sampling_offsets,
-                                  const float *attn_logits, int batch, int spatial_size, int num_heads,
+                                  const float *attn_logits, int level_major, int offsets_query_stride,
+                                  int logits_query_stride, int batch, int spatial_size, int num_heads,
                                   int channels, int num_levels, int num_query, int num_point, float *out);
 
 /* ---- Multi-scale deformable attention, backward -----------------------------------------------

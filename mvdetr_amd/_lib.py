@@ -15,13 +15,13 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
 _MSDA_BWD = [_vp] * 7 + [_i] * 7 + [_vp] * 3
 _WARP = [_vp] * 3 + [_i] * 7 + [_vp]
-_MSDA_FUSED = [_vp] * 5 + [ctypes.c_int64] + [_vp] * 2 + [_i] * 7 + [_vp]
+_MSDA_FUSED = [_vp] * 5 + [ctypes.c_int64] + [_vp] * 2 + [_i] * 10 + [_vp]
 
 SIGNATURES = {
     "mvdetr_ops_abi_version": ([], _i),

@@ -28,7 +28,8 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
 // fused variant: reference points + raw offsets + raw logits (see msda_forward_tile.hip)
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
-                            int B, int S, int M, int D, int L, float *out);
+                            int level_major, int qstride_l, int qstride_w, int B, int S, int M, int D, int L,
+                            float *out);
 
 template <typename T>
 inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *aw, const T *out, int B,

@@ -171,10 +171,16 @@ int mvdetr_msda_fused_supported(int batch, int spatial_size, int num_heads, int 
 int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_t *spatial_shapes,
                                   const int64_t *level_start_index, const float *reference_points,
                                   int64_t ref_batch_stride, const float *sampling_offsets,
-                                  const float *attn_logits, int batch, int spatial_size, int num_heads,
+                                  const float *attn_logits, int level_major, int offsets_query_stride,
+                                  int logits_query_stride, int batch, int spatial_size, int num_heads,
                                   int channels, int num_levels, int num_query, int num_point, float *out)
 {
     using namespace mvdetr;
+    const int dense_l = num_heads * num_levels * num_point * 2, dense_w = num_heads * num_levels * num_point;
+    if (offsets_query_stride == 0) offsets_query_stride = dense_l;
+    if (logits_query_stride == 0) logits_query_stride = dense_w;
+    if (offsets_query_stride < dense_l || logits_query_stride < dense_w || offsets_query_stride % 4 || logits_query_stride % 4)
+        return (int)hipErrorInvalidValue;
     if (bad_dims(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
         return (int)hipErrorInvalidValue;
     if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !out)
@@ -186,8 +192,9 @@ int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_
         return (int)hipErrorNotSupported;
     g_last_impl = "tile_fused";
     return msda_forward_tile_fused(reinterpret_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
-                                   reference_points, ref_batch_stride, sampling_offsets, attn_logits, batch,
-                                   spatial_size, num_heads, channels, num_levels, out);
+                                   reference_points, ref_batch_stride, sampling_offsets, attn_logits,
+                                   level_major ? 1 : 0, offsets_query_stride, logits_query_stride, batch, spatial_size,
+                                   num_heads, channels, num_levels, out);
 }
 
 int mvdetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,

@@ -50,12 +50,22 @@ __device__ __forceinline__ void fma4(float2v &lo, float2v &hi, float w, const fl
 // FUSED: `loc` holds the raw sampling offsets (output of the module's sampling_offsets Linear, pixels of
 // the sampled level) and `aw` the raw attention logits; the kernel adds the reference points
 // (`ref` [.., Lq, L, P, 2], batch stride `ref_bstride`, 0 = shared) and takes the softmax over L*P itself --
-// the arithmetic of ms_deform_attn.py:100-107 -- so neither tensor is materialised.
+// the arithmetic of ms_deform_attn.py:100-107 -- so neither tensor is materialised.  With `level_major` the
+// two raw tensors are laid out [B, Lq, L, M, P(, 2)] instead of the reference's [B, Lq, M, L, P(, 2)]: a free
+// permutation of the Linear's weight rows on the module side, which puts what ONE level iteration of the
+// heads of a tile needs into the same cache lines (the head-major layout spreads a line over 4 level
+// iterations, between which it falls out of L2).
+struct SamplingLayout {
+    int q_l, h_l, l_l;      // floats between consecutive queries / heads / levels of the locations (offsets)
+    int q_w, h_w, l_w;      // ... of the weights (logits)
+};
+
 template <typename Cfg, bool FUSED>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
-    const float *__restrict__ ref, int64_t ref_bstride, int B, int S, int M, int L, float *__restrict__ out)
+    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M, int L,
+    float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
     constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
@@ -128,8 +138,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
         const bool active = qy < Hq && qx < Wq;
         const int64_t q = lsi[lq] + (int64_t)qy * Wq + qx;          // query index == token index
         const int64_t bqm = active ? (((int64_t)b * S + q) * M + head) : 0;
-        const float *lp = loc + bqm * L * P * 2;
-        const float *wp = aw + bqm * L * P;
+        // sampling data of this (query, head): element (query, head, level) of `loc` starts at
+        // query * lay.q_l + head * lay.h_l + level * lay.l_l floats (`aw`: the *_w strides).  The reference
+        // layout [.., Lq, M, L, P(, 2)] and the level-major / column-block layouts of the fused path are all
+        // instances of it; the host fills the strides in.
+        const int lstep_l = lay.l_l, lstep_w = lay.l_w;
+        const int64_t bq = active ? (int64_t)b * S + q : 0;
+        const float *lp = loc + bq * lay.q_l + head * lay.h_l;
+        const float *wp = aw + bq * lay.q_w + head * lay.h_w;
         const float *rp = FUSED ? ref + b * ref_bstride + (active ? q : 0) * L * P * 2 : nullptr;
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;   // this slice of token 0
 
@@ -172,9 +188,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
         // and the reference points, turned into locations / weights where they are used
         float4 la = make_float4(0, 0, 0, 0), lb = la, wa = la, ra = la, rb = la;
         auto load_level = [&](int l, float4 &a, float4 &b2, float4 &w, float4 &r0, float4 &r1) {
-            a = *reinterpret_cast<const float4 *>(lp + l * P * 2);
-            b2 = *reinterpret_cast<const float4 *>(lp + l * P * 2 + 4);
-            w = *reinterpret_cast<const float4 *>(wp + l * P);
+            a = *reinterpret_cast<const float4 *>(lp + l * lstep_l);
+            b2 = *reinterpret_cast<const float4 *>(lp + l * lstep_l + 4);
+            w = *reinterpret_cast<const float4 *>(wp + l * lstep_w);
             if constexpr (FUSED) {
                 r0 = *reinterpret_cast<const float4 *>(rp + l * P * 2);
                 r1 = *reinterpret_cast<const float4 *>(rp + l * P * 2 + 4);
@@ -294,11 +310,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
             if constexpr (FUSED) {
                 if (active) {                             // plain two-pass statistics for the direct path
                     for (int l = 0; l < L; ++l) {
-                        const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
+                        const float4 w = *reinterpret_cast<const float4 *>(wp + l * lstep_w);
                         smax = fmaxf(smax, fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
                     }
                     for (int l = 0; l < L; ++l) {
-                        const float4 w = *reinterpret_cast<const float4 *>(wp + l * P);
+                        const float4 w = *reinterpret_cast<const float4 *>(wp + l * lstep_w);
                         ssum += __expf(w.x - smax) + __expf(w.y - smax) + __expf(w.z - smax) + __expf(w.w - smax);
                     }
                 }
@@ -312,7 +328,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
                 miss &= miss - 1;
                 const int l = bit / P;
                 const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-                float lx = lp[bit * 2 + 0], ly = lp[bit * 2 + 1], a = wp[bit];
+                const int pp = bit - l * P;
+                float lx = lp[l * lstep_l + pp * 2 + 0], ly = lp[l * lstep_l + pp * 2 + 1], a = wp[l * lstep_w + pp];
                 if constexpr (FUSED) {
                     lx = rp[bit * 2 + 0] + lx * (1.f / (float)W);
                     ly = rp[bit * 2 + 1] + ly * (1.f / (float)H);
@@ -370,8 +387,8 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
 
 template <typename Cfg, bool FUSED>
 static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
-                       const float *loc, const float *aw, const float *ref, int64_t ref_bstride, int B, int S,
-                       int M, int L, float *out)
+                       const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
+                       int B, int S, int M, int L, float *out)
 {
     static int blocks = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>),
@@ -387,7 +404,7 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
     }();
     hipLaunchKernelGGL((msda_fwd_tile<Cfg, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
-                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out);
+                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, B, S, M, L, out);
     return (int)hipGetLastError();
 }
 
@@ -400,18 +417,16 @@ static bool narrow_slices()
     return v;
 }
 
+#define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, B, S, M, L, out
+
 template <bool FUSED>
 static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
-                         const float *loc, const float *aw, const float *ref, int64_t ref_bstride, int B, int S,
-                         int M, int D, int L, float *out)
+                         const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
+                         int B, int S, int M, int D, int L, float *out)
 {
     const bool narrow = narrow_slices();
-    if (D == 16)
-        return narrow ? launch_tile<CfgNarrow16, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out)
-                      : launch_tile<CfgWide16, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out);
-    if (D == 32)
-        return narrow ? launch_tile<CfgNarrow32, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out)
-                      : launch_tile<CfgWide32, FUSED>(st, value, shapes, lsi, loc, aw, ref, ref_bstride, B, S, M, L, out);
+    if (D == 16) return narrow ? launch_tile<CfgNarrow16, FUSED>(TILE_ARGS) : launch_tile<CfgWide16, FUSED>(TILE_ARGS);
+    if (D == 32) return narrow ? launch_tile<CfgNarrow32, FUSED>(TILE_ARGS) : launch_tile<CfgWide32, FUSED>(TILE_ARGS);
     return (int)hipErrorInvalidValue;
 }
 
@@ -419,14 +434,20 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
                       int P, float *out)
 {
-    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, B, S, M, D, L, out);
+    const SamplingLayout lay = {M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P};     // [.., Lq, M, L, P(, 2)]
+    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, B, S, M, D, L, out);
 }
 
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
-                            int B, int S, int M, int D, int L, float *out)
+                            int level_major, int qstride_l, int qstride_w, int B, int S, int M, int D, int L,
+                            float *out)
 {
-    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, B, S, M, D, L, out);
+    const int P = TILE_P;
+    const SamplingLayout lay = level_major
+        ? SamplingLayout{qstride_l, P * 2, M * P * 2, qstride_w, P, M * P}              // [.., Lq, L, M, P(, 2)]
+        : SamplingLayout{qstride_l, L * P * 2, P * 2, qstride_w, L * P, P};             // [.., Lq, M, L, P(, 2)]
+    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay, B, S, M, D, L, out);
 }
 
 }  // namespace mvdetr

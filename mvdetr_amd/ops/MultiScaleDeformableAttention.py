@@ -99,15 +99,30 @@ def fused_supported(value, num_levels, num_query, num_point) -> bool:
 
 
 def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                                 attn_logits):
+                                 attn_logits, level_major=False):
     """Core + the module arithmetic around it (ms_deform_attn.py:100-107) in one kernel (inference):
     value [B,S,M,D]; reference_points [B or 1, Lq, L, P, 2] (may be a batch-expanded view);
-    sampling_offsets [B,Lq,M,L,P,2] and attn_logits [B,Lq,M,L,P] are the raw Linear outputs.
-    -> [B, Lq, M*D].  No extension counterpart in the reference: this is SURVEY row f1."""
-    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
-                   ("sampling_offsets", sampling_offsets), ("attn_logits", attn_logits)])
+    sampling_offsets [B,Lq,M,L,P,2] and attn_logits [B,Lq,M,L,P] are the raw Linear outputs
+    ([B,Lq,L,M,P,2] / [B,Lq,L,M,P] with ``level_major``); each may be a column block of a wider GEMM
+    output (dense per query, arbitrary query stride).  -> [B, Lq, M*D].
+    No extension counterpart in the reference: this is SURVEY row f1."""
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index)])
     B, S, M, D = value.shape
     L, Lq, P = spatial_shapes.shape[0], sampling_offsets.shape[1], sampling_offsets.shape[4]
+    if tuple(sampling_offsets.shape[2:4]) != ((L, M) if level_major else (M, L)):
+        raise RuntimeError("sampling_offsets layout does not match level_major")
+    qstrides = []
+    for name, t, inner in (("sampling_offsets", sampling_offsets, M * L * P * 2), ("attn_logits", attn_logits, M * L * P)):
+        if not t.is_cuda or t.dtype != value.dtype:
+            raise RuntimeError(f"{name} must be a CUDA tensor of value's dtype")
+        flat = t.reshape(B, Lq, inner) if t.is_contiguous() else t
+        if not t.is_contiguous():
+            # accept a column block [..., a:b] of a [B, Lq, K] GEMM output, viewed as [B, Lq, ., ., .(, 2)]
+            st = t.stride()
+            dense_inner = all(st[i] == st[i + 1] * t.shape[i + 1] for i in range(2, t.dim() - 1)) and st[-1] == 1
+            if not dense_inner or st[0] != st[1] * Lq:
+                raise RuntimeError(f"{name} tensor has to be contiguous per query")
+        qstrides.append(t.stride(1))
     if reference_points.shape[-4:] != (Lq, L, P, 2) or not reference_points.is_cuda:
         raise RuntimeError("reference_points must be a CUDA tensor of shape [B or 1, Lq, L, P, 2]")
     if not reference_points[0].is_contiguous():
@@ -119,7 +134,8 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
         rc = _lib.lib().mvdetr_msda_forward_fused_f32(
             _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), reference_points.data_ptr(), rstride, sampling_offsets.data_ptr(),
-            attn_logits.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr())
+            attn_logits.data_ptr(), 1 if level_major else 0, qstrides[0], qstrides[1], B, S, M, D, L, Lq, P,
+            out.data_ptr())
     _lib.check(rc, "ms_deform_attn_forward_fused")
     return out
 

@@ -44,6 +44,7 @@ class MSDeformAttn(nn.Module):
         self._validated = None
         # inference calls of deformable-encoder shape run softmax + location arithmetic inside the kernel
         self.fused_inference = True
+        self._fused_cache = None
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -63,6 +64,23 @@ class MSDeformAttn(nn.Module):
         nn.init.constant_(self.value_proj.bias.data, 0.0)
         nn.init.xavier_uniform_(self.output_proj.weight.data)
         nn.init.constant_(self.output_proj.bias.data, 0.0)
+
+    def _fused_projection(self):
+        """Weights of ONE Linear producing [offsets | logits] with output rows reordered from the reference's
+        (head, level, point) to (level, head, point): a free change of the output layout that lets the kernel
+        read what one level iteration needs from the same cache lines.  Cached until a parameter changes."""
+        ps = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
+              self.attention_weights.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._fused_cache is None or self._fused_cache[0] != key:
+            M, L, P, C = self.n_heads, self.n_levels, self.n_points, self.d_model
+            with torch.no_grad():
+                ow = ps[0].view(M, L, P * 2, C).transpose(0, 1).reshape(M * L * P * 2, C)
+                ob = ps[1].view(M, L, P * 2).transpose(0, 1).reshape(-1)
+                aw = ps[2].view(M, L, P, C).transpose(0, 1).reshape(M * L * P, C)
+                ab = ps[3].view(M, L, P).transpose(0, 1).reshape(-1)
+                self._fused_cache = (key, torch.cat([ow, aw], 0).contiguous(), torch.cat([ob, ab], 0).contiguous())
+        return self._fused_cache[1], self._fused_cache[2]
 
     def _check_lengths(self, spatial_shapes, len_in):
         # the reference asserts sum(H*W) == Len_in on every call (ms_deform_attn.py:94), which is a
@@ -86,15 +104,22 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
-        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
         if (self.fused_inference and reference_points.shape[-1] == 2 and reference_points.dim() == 5
-                and not (torch.is_grad_enabled() and (value.requires_grad or offsets.requires_grad))
+                and not (torch.is_grad_enabled() and (value.requires_grad or query.requires_grad
+                                                      or self.sampling_offsets.weight.requires_grad))
                 and MSDA.fused_supported(value, self.n_levels, Len_q, self.n_points)):
+            # one GEMM for offsets + logits, rows permuted to level-major (see _fused_projection)
+            w, b = self._fused_projection()
+            raw = F.linear(query, w, b)
+            n_off = self.n_heads * self.n_levels * self.n_points * 2
+            L, M, P = self.n_levels, self.n_heads, self.n_points
             out = MSDA.ms_deform_attn_forward_fused(
                 value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,
-                offsets.contiguous(), weights.view(N, Len_q, self.n_heads, self.n_levels, self.n_points).contiguous())
+                raw[..., :n_off].unflatten(-1, (L, M, P, 2)), raw[..., n_off:].unflatten(-1, (L, M, P)),
+                level_major=True)
             return self.output_proj(out)
+        offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
         weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
