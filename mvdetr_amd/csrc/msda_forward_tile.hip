@@ -172,7 +172,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
             const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
 #pragma unroll
             for (int i = 0; i < NSTAGE; ++i) {
-                const int wy = my_row0 + i * Cfg::ROWS_PER_PASS;
+                // one row per pass (128-byte slices): the row index is a compile-time constant, so the row
+                // offset and its bounds test are scalar (SALU) instead of 64-bit vector multiplies per load
+                const int wy = Cfg::ROWS_PER_PASS == 1 ? i : my_row0 + i * Cfg::ROWS_PER_PASS;
                 const int gy = oy + wy;
                 stage[i] = make_float4(0, 0, 0, 0);
                 if (xok && wy < WH && (unsigned)gy < (unsigned)H)
