@@ -1,0 +1,284 @@
+// Multi-scale deformable attention forward, fused + camera-grouped LDS-tiled kernel -- gfx950 (MI355X).
+//
+// What bounds msda_fwd_tile is the window staging: every (tile, slice, QUERY level) workgroup copies the
+// same L source windows into LDS -- 1.35 GB of L2->LDS traffic per launch at Wildtrack size against 0.28 GB
+// of algorithmic bytes -- and pays two barriers per level for 4 taps per lane.  In MVDeTr all levels
+// (cameras) have the same shape and a cell's queries of all L cameras sample the same windows, so here one
+// workgroup owns a (tile, slice) and walks ALL NG = L query levels per staged window: staging, window writes
+// and barriers drop by L, the taps per barrier rise by L.  That needs the sampling data of (camera, level)
+// when level's window is resident, which the reference layout [Lq, M, L, P] scatters over the tensor; the
+// fused path's level-major raw layout [Lq, L, M, P] (a row permutation of the module's Linear) makes it one
+// contiguous run per query -- so this kernel exists for the FUSED entry point only.
+//
+// Lane = (cell, half slice) as in the tile kernel, but with NG accumulator sets (one per camera) and NG
+// online-softmax states.  The window copy is synchronous (its latency is now amortised over NG x 4 taps),
+// which is what frees the registers for the accumulators.
+//
+// Shapes live on the device, so the kernel itself checks that the levels are equal and returns at once if
+// not; the launcher then relies on msda_fwd_tile (launched right after with `defer_equal` set, which makes
+// THAT kernel return at once when the levels ARE equal).  Exactly one of the two does the work.
+#include "common.h"
+#include "msda_dispatch.h"
+#include "msda_tile.h"
+#include <stdlib.h>
+
+namespace mvdetr {
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void gfma4(float2v &lo, float2v &hi, float w, const float4 &c)
+{
+    const float2v ww = {w, w};
+    lo = __builtin_elementwise_fma(ww, (float2v){c.x, c.y}, lo);
+    hi = __builtin_elementwise_fma(ww, (float2v){c.z, c.w}, hi);
+}
+
+template <typename Cfg, int NG>
+__global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_group(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
+    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M,
+    float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) float win[];
+    constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
+    constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = Cfg::NV, NSTAGE = Cfg::NSTAGE, LCH = SLICE / 2, L = NG;
+    static_assert(Cfg::ROWS_PER_PASS == 1, "written for 128-byte slices (one window row per copy pass)");
+    const int tid = threadIdx.x;
+    const int HS = M * D / SLICE;
+    const int row = M * D;
+
+    for (int l = 1; l < L; ++l)
+        if (shapes[2 * l] != shapes[0] || shapes[2 * l + 1] != shapes[1]) return;     // not ours (see header)
+    const int Hq = (int)shapes[0], Wq = (int)shapes[1];
+    const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
+    const int jobs = per_level * HS * B, jobs8 = (jobs + 7) / 8;
+
+    const int sub = tid & 1, qi = tid >> 1;
+    const int qly = qi / TW, qlx = qi % TW;
+    const int rot = (qlx / Cfg::TOK_PER_BANKROW) & (NV - 1);
+    const int lane_off = sub * LCH;
+    const int my_part = tid % Cfg::PARTS, my_col = tid / Cfg::PARTS;
+    const bool col_ok = my_col < WW;
+    float *const st_dst = win + my_col * SLICE + my_part * 4;
+
+    for (int t = blockIdx.x; t < jobs8 * 8; t += gridDim.x) {
+        const int job = (t & 7) * jobs8 + (t >> 3);          // XCD k takes a contiguous band of jobs
+        if ((t >> 3) >= jobs8 || job >= jobs) continue;
+        const int hs = job % HS, u2 = job / HS;
+        const int tin = u2 % per_level, b = u2 / per_level;
+        const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
+        const int ch0 = hs * SLICE + lane_off;
+        const int head = ch0 / D, ch_off = ch0 % D;
+        const int qy = Y0 + qly, qx = X0 + qlx;
+        const bool active = qi < TH * TW && qy < Hq && qx < Wq;
+        // per-lane part of the sampling-data addresses (cell, head); camera c adds (b*S + lsi[c]) queries
+        const int64_t cell = active ? (int64_t)qy * Wq + qx : 0;
+        const float *lp0 = off + cell * lay.q_l + head * lay.h_l;
+        const float *wp0 = logit + cell * lay.q_w + head * lay.h_w;
+        const float *rp0 = ref + b * ref_bstride + cell * L * P * 2;
+        auto cam_q = [&](int c) { return (int64_t)b * S + lsi[c]; };          // wave-uniform
+        const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
+
+        float2v acc[NG][2 * NV];
+        float smax[NG], ssum[NG];
+        unsigned miss[NG];
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+#pragma unroll
+            for (int i = 0; i < 2 * NV; ++i) acc[c][i] = (float2v){0.f, 0.f};
+            smax[c] = -INFINITY;
+            ssum[c] = 0.f;
+            miss[c] = 0u;
+        }
+
+        for (int l = 0; l < L; ++l) {
+            // window of level l around the tile (all levels have the query level's shape)
+            const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+            const float fW = (float)Wq, fH = (float)Hq, iw = 1.f / fW, ih = 1.f / fH;
+            const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
+            __syncthreads();                                  // everyone is done reading the old window
+            {
+                const int gx = ox + my_col;
+                const bool xok = col_ok && (unsigned)gx < (unsigned)Wq;
+                const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
+                float4 stage[NSTAGE];
+#pragma unroll
+                for (int i = 0; i < NSTAGE; ++i) {
+                    const int gy = oy + i;
+                    stage[i] = make_float4(0, 0, 0, 0);
+                    if (xok && (unsigned)gy < (unsigned)Hq)
+                        stage[i] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * Wq * row);
+                }
+                if (col_ok) {
+#pragma unroll
+                    for (int i = 0; i < NSTAGE; ++i)
+                        *reinterpret_cast<float4 *>(st_dst + i * WW * SLICE) = stage[i];
+                }
+            }
+            __syncthreads();
+
+            if (active) {
+                // sampling data of (camera, level): raw offsets (2 x float4), raw logits, reference points;
+                // camera c+1's loads are in flight while camera c's taps run
+                float4 na, nb, nw, nra, nrb;
+                auto load_cam = [&](int c) {
+                    const int64_t cq = cam_q(c);
+                    const float *lp = lp0 + cq * lay.q_l + l * lay.l_l;
+                    na = *reinterpret_cast<const float4 *>(lp);
+                    nb = *reinterpret_cast<const float4 *>(lp + 4);
+                    nw = *reinterpret_cast<const float4 *>(wp0 + cq * lay.q_w + l * lay.l_w);
+                    const float *rp = rp0 + (cq - (int64_t)b * S) * L * P * 2 + l * P * 2;
+                    nra = *reinterpret_cast<const float4 *>(rp);
+                    nrb = *reinterpret_cast<const float4 *>(rp + 4);
+                };
+                load_cam(0);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    float4 la = na, lb = nb, wa = nw;
+                    const float4 ra = nra, rb = nrb;
+                    if (c + 1 < NG) load_cam(c + 1);
+                    // fold this level's logits into camera c's running softmax
+                    const float m = fmaxf(smax[c], fmaxf(fmaxf(wa.x, wa.y), fmaxf(wa.z, wa.w)));
+                    const float sc = __expf(smax[c] - m);
+                    wa = make_float4(__expf(wa.x - m), __expf(wa.y - m), __expf(wa.z - m), __expf(wa.w - m));
+                    ssum[c] = ssum[c] * sc + (wa.x + wa.y) + (wa.z + wa.w);
+                    smax[c] = m;
+                    const float2v scv = {sc, sc};
+#pragma unroll
+                    for (int i = 0; i < 2 * NV; ++i) acc[c][i] *= scv;
+                    // pixel coordinates: (ref + off / size) * size - 0.5
+                    const float xs[4] = {(ra.x + la.x * iw) * fW - 0.5f, (ra.z + la.z * iw) * fW - 0.5f,
+                                         (rb.x + lb.x * iw) * fW - 0.5f, (rb.z + lb.z * iw) * fW - 0.5f};
+                    const float ys[4] = {(ra.y + la.y * ih) * fH - 0.5f, (ra.w + la.w * ih) * fH - 0.5f,
+                                         (rb.y + lb.y * ih) * fH - 0.5f, (rb.w + lb.w * ih) * fH - 0.5f};
+                    const float aws[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float x = xs[p], y = ys[p];
+                        if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
+                            const float fx = floorf(x), fy = floorf(y);
+                            const int ix = (int)fx - ox, iy = (int)fy - oy;
+                            const float wx1 = x - fx, wy1 = y - fy, a = aws[p];
+                            const float ay1 = wy1 * a, ay0 = a - ay1;
+                            const float w01 = ay0 * wx1, w00 = ay0 - w01, w11 = ay1 * wx1, w10 = ay1 - w11;
+                            const float *p00 = win + __mul24(iy * WW + ix, SLICE) + lane_off;
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) {
+                                const float *pk = p00 + ((k ^ rot) << 2);
+                                const float4 c00 = *reinterpret_cast<const float4 *>(pk);
+                                const float4 c01 = *reinterpret_cast<const float4 *>(pk + SLICE);
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w00, c00);
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w01, c01);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);    // at most 8 LDS reads in flight
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) {
+                                const float *pk = p00 + WW * SLICE + ((k ^ rot) << 2);
+                                const float4 c10 = *reinterpret_cast<const float4 *>(pk);
+                                const float4 c11 = *reinterpret_cast<const float4 *>(pk + SLICE);
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w10, c10);
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w11, c11);
+                            }
+                        } else {
+                            miss[c] |= 1u << (l * P + p);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                const int64_t cq = cam_q(c);
+                const float *lp = lp0 + cq * lay.q_l, *wp = wp0 + cq * lay.q_w, *rp = rp0 + lsi[c] * L * P * 2;
+                unsigned mm = miss[c];
+                // taps that left the window: straight from global memory (zero padding by test)
+                while (mm) {
+                    const int bit = __ffs((int)mm) - 1;
+                    mm &= mm - 1;
+                    const int l = bit / P, pp = bit - l * P;
+                    const float fW = (float)Wq, fH = (float)Hq;
+                    const float x = (rp[bit * 2 + 0] + lp[l * lay.l_l + pp * 2 + 0] * (1.f / fW)) * fW - 0.5f;
+                    const float y = (rp[bit * 2 + 1] + lp[l * lay.l_l + pp * 2 + 1] * (1.f / fH)) * fH - 0.5f;
+                    const float a = __expf(wp[l * lay.l_w + pp] - smax[c]);
+                    if (!(y > -1.f && x > -1.f && y < fH && x < fW)) continue;
+                    const Footprint<float> f = footprint(y, x, Hq, Wq);
+                    const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * Wq + f.x0) * row;
+                    const float *r1 = r0 + (int64_t)Wq * row;
+                    const float w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a;
+                    const float w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        const int ko = (k ^ rot) << 2;
+                        const float4 z = make_float4(0, 0, 0, 0);
+                        const float4 c00 = (f.vy0 && f.vx0) ? *reinterpret_cast<const float4 *>(r0 + ko) : z;
+                        const float4 c01 = (f.vy0 && f.vx1) ? *reinterpret_cast<const float4 *>(r0 + row + ko) : z;
+                        const float4 c10 = (f.vy1 && f.vx0) ? *reinterpret_cast<const float4 *>(r1 + ko) : z;
+                        const float4 c11 = (f.vy1 && f.vx1) ? *reinterpret_cast<const float4 *>(r1 + row + ko) : z;
+                        gfma4(acc[c][2 * k], acc[c][2 * k + 1], w00, c00);
+                        gfma4(acc[c][2 * k], acc[c][2 * k + 1], w01, c01);
+                        gfma4(acc[c][2 * k], acc[c][2 * k + 1], w10, c10);
+                        gfma4(acc[c][2 * k], acc[c][2 * k + 1], w11, c11);
+                    }
+                }
+                const float inv = 1.f / ssum[c];
+                float *o = out + ((cq + cell) * M + head) * D + ch_off;
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    *reinterpret_cast<float4 *>(o + ((k ^ rot) << 2)) =
+                        make_float4(acc[c][2 * k].x * inv, acc[c][2 * k].y * inv, acc[c][2 * k + 1].x * inv,
+                                    acc[c][2 * k + 1].y * inv);
+            }
+        }
+    }
+}
+
+// 6-row tiles: 60 = 10 x 6 and 80 rows = 13.3 -> 14; (6+12) x 28 tokens x 128 B = 64.5 KB -> 2 workgroups / CU;
+// 480 jobs for 512 resident workgroups at Wildtrack size (8-row tiles would give 384)
+using GCfg16 = TileCfg<16, 32, 6, 16, 6, 256>;      // 192 compute lanes; all 256 move window columns (28 x 8 needed)
+using GCfg32 = TileCfg<32, 32, 6, 16, 6, 256>;
+
+template <typename Cfg, int NG>
+static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                        const float *off, const float *logit, const float *ref, int64_t ref_bstride,
+                        SamplingLayout lay, int B, int S, int M, float *out)
+{
+    static int blocks = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        int dev = 0, cus = 256, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG>, Cfg::THREADS,
+                                                         Cfg::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 2;
+        return (cus * per_cu + 7) / 8 * 8;
+    }();
+    hipLaunchKernelGGL((msda_fwd_group<Cfg, NG>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
+    return (int)hipGetLastError();
+}
+
+bool msda_group_supported(int D, int L)
+{
+    static const bool enabled = [] { const char *e = getenv("MVDETR_MSDA_GROUP"); return !(e && e[0] == '0'); }();
+    return enabled && (D == 16 || D == 32) && (L == 6 || L == 7);
+}
+
+int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                       const float *off, const float *logit, const float *ref, int64_t ref_bstride,
+                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out)
+{
+#define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out
+    if (D == 16 && L == 7) return launch_group<GCfg16, 7>(GROUP_ARGS);
+    if (D == 16 && L == 6) return launch_group<GCfg16, 6>(GROUP_ARGS);
+    if (D == 32 && L == 7) return launch_group<GCfg32, 7>(GROUP_ARGS);
+    if (D == 32 && L == 6) return launch_group<GCfg32, 6>(GROUP_ARGS);
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace mvdetr

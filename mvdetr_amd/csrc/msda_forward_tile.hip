@@ -55,17 +55,12 @@ __device__ __forceinline__ void fma4(float2v &lo, float2v &hi, float w, const fl
 // permutation of the Linear's weight rows on the module side, which puts what ONE level iteration of the
 // heads of a tile needs into the same cache lines (the head-major layout spreads a line over 4 level
 // iterations, between which it falls out of L2).
-struct SamplingLayout {
-    int q_l, h_l, l_l;      // floats between consecutive queries / heads / levels of the locations (offsets)
-    int q_w, h_w, l_w;      // ... of the weights (logits)
-};
-
 template <typename Cfg, bool FUSED>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
-    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M, int L,
-    float *__restrict__ out)
+    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int defer_equal, int B, int S,
+    int M, int L, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
     constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
@@ -81,6 +76,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
         tiles_spatial += tiles_of_level<Cfg>(shapes, l);
         equal_shapes = equal_shapes && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
     }
+    if (defer_equal && equal_shapes) return;              // the camera-grouped kernel took this call
     const int per_level = equal_shapes ? tiles_spatial / L : 0;
     const int units = per_level * HS * B;                 // (tile, slice, batch) units, equal shapes only
     const int units8 = (units + 7) / 8;                   // units per XCD
@@ -390,7 +386,7 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
 template <typename Cfg, bool FUSED>
 static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
-                       int B, int S, int M, int L, float *out)
+                       int defer_equal, int B, int S, int M, int L, float *out)
 {
     static int blocks = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>),
@@ -406,7 +402,7 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
     }();
     hipLaunchKernelGGL((msda_fwd_tile<Cfg, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
-                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, B, S, M, L, out);
+                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, defer_equal, B, S, M, L, out);
     return (int)hipGetLastError();
 }
 
@@ -419,12 +415,12 @@ static bool narrow_slices()
     return v;
 }
 
-#define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, B, S, M, L, out
+#define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, defer_equal, B, S, M, L, out
 
 template <bool FUSED>
 static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
-                         int B, int S, int M, int D, int L, float *out)
+                         int defer_equal, int B, int S, int M, int D, int L, float *out)
 {
     const bool narrow = narrow_slices();
     if (D == 16) return narrow ? launch_tile<CfgNarrow16, FUSED>(TILE_ARGS) : launch_tile<CfgWide16, FUSED>(TILE_ARGS);
@@ -437,7 +433,7 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
                       int P, float *out)
 {
     const SamplingLayout lay = {M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P};     // [.., Lq, M, L, P(, 2)]
-    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, B, S, M, D, L, out);
+    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, 0, B, S, M, D, L, out);
 }
 
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -449,7 +445,16 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     const SamplingLayout lay = level_major
         ? SamplingLayout{qstride_l, P * 2, M * P * 2, qstride_w, P, M * P}              // [.., Lq, L, M, P(, 2)]
         : SamplingLayout{qstride_l, L * P * 2, P * 2, qstride_w, L * P, P};             // [.., Lq, M, L, P(, 2)]
-    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay, B, S, M, D, L, out);
+    // MVDeTr's camera counts: the camera-grouped kernel does the work when the levels turn out (on the
+    // device) to have equal shapes, this file's kernel when they do not -- see msda_forward_group.hip
+    int defer_equal = 0;
+    if (msda_group_supported(D, L) && !narrow_slices()) {
+        const int rc = msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay, B, S, M, D, L, out);
+        if (rc != 0) return rc;
+        defer_equal = 1;
+    }
+    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay, defer_equal, B, S, M, D,
+                               L, out);
 }
 
 }  // namespace mvdetr

@@ -8,14 +8,15 @@ namespace mvdetr {
 constexpr int TILE_MAX_LEVELS = 16;     // 64-bit miss mask = L * P bits with P == 4
 constexpr int TILE_P = 4;
 
-template <int D_, int SLICE_, int TH_, int TW_, int R_> struct TileCfg {
+template <int D_, int SLICE_, int TH_, int TW_, int R_, int THREADS_ = TH_ * TW_ * 2> struct TileCfg {
     static constexpr int D = D_, TH = TH_, TW = TW_, R = R_;
     static constexpr int SLICE = SLICE_;              // floats of a token row staged per workgroup (32 = 128 B, 16 = 64 B)
     static constexpr int SUBS = 2;                    // lanes per query, each owning half a slice
     static constexpr int NV = SLICE / SUBS / 4;       // 16-byte chunks (float4 accumulators) per lane
     static constexpr int PARTS = SLICE / 4;           // float4 per token in LDS
     static constexpr int WH = TH + 2 * R, WW = TW + 2 * R;
-    static constexpr int THREADS = TH * TW * SUBS;
+    static constexpr int THREADS = THREADS_;          // >= TH*TW*SUBS compute lanes; the surplus only helps the window copy
+    static_assert(THREADS_ >= TH_ * TW_ * 2 && THREADS_ % 64 == 0, "whole waves covering the tile");
     static constexpr int COLSLOTS = THREADS / PARTS;  // window columns a copy pass covers ...
     static constexpr int ROWS_PER_PASS = COLSLOTS / WW;   // ... i.e. this many whole rows
     static constexpr int NSTAGE = (WH + ROWS_PER_PASS - 1) / ROWS_PER_PASS;   // float4 per lane per window
@@ -32,6 +33,20 @@ template <int D_, int SLICE_, int TH_, int TW_, int R_> struct TileCfg {
     static_assert(D % (SLICE / SUBS) == 0, "a lane's channels must lie inside one head");
     static_assert(ROWS_PER_PASS >= 1, "window copy: one pass must cover at least one row");
 };
+
+// Where element (query, head, level) of the sampling locations / weights starts: query * q + head * h +
+// level * l floats.  Covers the reference layout [.., Lq, M, L, P(, 2)] and the fused path's level-major and
+// column-block layouts; filled in by the host.
+struct SamplingLayout {
+    int q_l, h_l, l_l;      // locations (or raw offsets)
+    int q_w, h_w, l_w;      // weights (or raw logits)
+};
+
+// camera-grouped fused forward (msda_forward_group.hip)
+bool msda_group_supported(int D, int L);
+int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                       const float *off, const float *logit, const float *ref, int64_t ref_bstride,
+                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out);
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
 // scalar registers).

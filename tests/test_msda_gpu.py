@@ -465,7 +465,8 @@ def _module_with_random_projections(d_model, L, M, P, seed):
     return mod
 
 
-@pytest.mark.parametrize("L,H,W,B,d_model", [(7, 21, 43, 1, 128), (3, 16, 24, 2, 128), (16, 9, 17, 1, 256), (4, 40, 64, 1, 128)])
+@pytest.mark.parametrize("L,H,W,B,d_model", [(7, 21, 43, 1, 128), (3, 16, 24, 2, 128), (16, 9, 17, 1, 256), (4, 40, 64, 1, 128),
+                                             (6, 20, 31, 2, 128), (7, 13, 19, 1, 256), (7, 6, 16, 1, 128), (6, 61, 35, 1, 128)])
 def test_fused_module_forward_vs_oracle_and_unfused(ops, L, H, W, B, d_model):
     _, MSDA = ops
     M, P = 8, 4
@@ -515,3 +516,27 @@ def test_fused_path_is_inference_only_and_training_still_matches(ops):
         out2 = mod(query, ref, query, shapes, level_start_index(shapes))
     assert MSDA.last_forward_impl() == "tile_fused"
     assert (out2 - out.detach()).abs().max().item() < 2e-5
+
+
+def test_fused_seven_unequal_levels_take_the_tile_kernel(ops):
+    """L = 7 selects the camera-grouped kernel on the host, but the shapes (device-side) are unequal: the
+    grouped kernel must stand down and the tile kernel must do the work."""
+    from helpers import pyramid_encoder_inputs
+    _, MSDA = ops
+    lv = [(12, 20), (6, 10), (12, 20), (3, 5), (8, 8), (12, 20), (5, 9)]
+    value, shapes, lsi, _, _ = pyramid_encoder_inputs(lv, M=8, D=16, seed=3)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(5)
+    off = torch.randn(1, S, 7, 8, 4, 2, generator=g) * 1.5            # level-major raw offsets (pixels)
+    logit = torch.randn(1, S, 7, 8, 4, generator=g)
+    refs = []
+    for H, W in lv:
+        ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+        refs.append(torch.stack([xs / W, ys / H], -1).reshape(-1, 2))
+    ref = torch.cat(refs, 0).view(1, S, 1, 1, 2).repeat(1, 1, 7, 4, 1)
+    out = MSDA.ms_deform_attn_forward_fused(*dev(value, shapes, lsi, ref, off, logit), level_major=True).cpu()
+    off_hm, logit_hm = off.permute(0, 1, 3, 2, 4, 5), logit.permute(0, 1, 3, 2, 4)
+    loc = torch_oracle.msda_sampling_locations(ref, off_hm, shapes)
+    aw = torch.softmax(logit_hm.flatten(3), -1).view(1, S, 8, 7, 4)
+    want = torch_oracle.msda_core(value, shapes, loc, aw)
+    assert (out - want).abs().max().item() < FP32_TOL
