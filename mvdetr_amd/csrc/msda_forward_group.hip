@@ -14,17 +14,16 @@
 // online-softmax states.  The window copy is synchronous (its latency is now amortised over NG x 4 taps),
 // which is what frees the registers for the accumulators.
 //
-// Shapes live on the device, so the kernel itself checks that the levels are equal and returns at once if
-// not; the launcher then relies on msda_fwd_tile (launched right after with `defer_equal` set, which makes
-// THAT kernel return at once when the levels ARE equal).  Exactly one of the two does the work.
+// Shapes live on the device, so the kernel itself checks that the levels are equal; if they are not, the
+// same launch runs the tile kernel's body instead (msda_tile_body.h) -- no second launch, no host knowledge.
 #include "common.h"
 #include "msda_dispatch.h"
 #include "msda_tile.h"
+#include "msda_tile_body.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace mvdetr {
-
-typedef float float2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void gfma4(float2v &lo, float2v &hi, float w, const float4 &c)
 {
@@ -33,8 +32,8 @@ __device__ __forceinline__ void gfma4(float2v &lo, float2v &hi, float w, const f
     hi = __builtin_elementwise_fma(ww, (float2v){c.z, c.w}, hi);
 }
 
-template <typename Cfg, int NG>
-__global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_group(
+template <typename Cfg, int NG, int WAVES>
+__global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
     const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M,
@@ -43,13 +42,18 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_gr
     extern __shared__ __attribute__((aligned(16))) float win[];
     constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
     constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = Cfg::NV, NSTAGE = Cfg::NSTAGE, LCH = SLICE / 2, L = NG;
-    static_assert(Cfg::ROWS_PER_PASS == 1, "written for 128-byte slices (one window row per copy pass)");
+    constexpr int RPP = Cfg::ROWS_PER_PASS;
     const int tid = threadIdx.x;
     const int HS = M * D / SLICE;
     const int row = M * D;
 
     for (int l = 1; l < L; ++l)
-        if (shapes[2 * l] != shapes[0] || shapes[2 * l + 1] != shapes[1]) return;     // not ours (see header)
+        if (shapes[2 * l] != shapes[0] || shapes[2 * l + 1] != shapes[1]) {            // not ours (see header)
+            using Fallback = TileCfg<Cfg::D, 32, 8, 16, 6>;
+            static_assert(Fallback::THREADS == Cfg::THREADS, "the fallback body runs on this launch's workgroups");
+            msda_fwd_tile_body<Fallback, true>(win, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, L, out);
+            return;
+        }
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
     const int jobs = per_level * HS * B, jobs8 = (jobs + 7) / 8;
@@ -58,9 +62,11 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_gr
     const int qly = qi / TW, qlx = qi % TW;
     const int rot = (qlx / Cfg::TOK_PER_BANKROW) & (NV - 1);
     const int lane_off = sub * LCH;
-    const int my_part = tid % Cfg::PARTS, my_col = tid / Cfg::PARTS;
-    const bool col_ok = my_col < WW;
-    float *const st_dst = win + my_col * SLICE + my_part * 4;
+    // window copy: thread moves float4 `my_part` of window column `my_col`, rows my_row0 + i * RPP
+    const int my_part = tid % Cfg::PARTS, my_slot = tid / Cfg::PARTS;
+    const int my_row0 = my_slot / WW, my_col = my_slot % WW;
+    const bool col_ok = my_row0 < RPP;
+    float *const st_dst = win + (my_row0 * WW + my_col) * SLICE + my_part * 4;
 
     for (int t = blockIdx.x; t < jobs8 * 8; t += gridDim.x) {
         const int job = (t & 7) * jobs8 + (t >> 3);          // XCD k takes a contiguous band of jobs
@@ -105,15 +111,17 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_gr
                 float4 stage[NSTAGE];
 #pragma unroll
                 for (int i = 0; i < NSTAGE; ++i) {
-                    const int gy = oy + i;
+                    const int wy = RPP == 1 ? i : my_row0 + i * RPP;       // RPP == 1: scalar row arithmetic
+                    const int gy = oy + wy;
                     stage[i] = make_float4(0, 0, 0, 0);
-                    if (xok && (unsigned)gy < (unsigned)Hq)
+                    if (xok && wy < WH && (unsigned)gy < (unsigned)Hq)
                         stage[i] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * Wq * row);
                 }
                 if (col_ok) {
 #pragma unroll
                     for (int i = 0; i < NSTAGE; ++i)
-                        *reinterpret_cast<float4 *>(st_dst + i * WW * SLICE) = stage[i];
+                        if ((RPP == 1 ? i : my_row0 + i * RPP) < WH)
+                            *reinterpret_cast<float4 *>(st_dst + i * RPP * WW * SLICE) = stage[i];
                 }
             }
             __syncthreads();
@@ -238,28 +246,33 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_gr
 
 // 6-row tiles: 60 = 10 x 6 and 80 rows = 13.3 -> 14; (6+12) x 28 tokens x 128 B = 64.5 KB -> 2 workgroups / CU;
 // 480 jobs for 512 resident workgroups at Wildtrack size (8-row tiles would give 384)
-using GCfg16 = TileCfg<16, 32, 6, 16, 6, 256>;      // 192 compute lanes; all 256 move window columns (28 x 8 needed)
-using GCfg32 = TileCfg<32, 32, 6, 16, 6, 256>;
+// Wide: 128-byte slices, 6-row tiles: (6+12) x 28 tokens x 128 B = 64.5 KB -> 2 workgroups / CU; 480 jobs for
+// 512 resident workgroups at Wildtrack size (8-row tiles would give 384).  192 compute lanes; all 256 move
+// window columns.
+using GWide16 = TileCfg<16, 32, 6, 16, 6, 256>;
+using GWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 
-template <typename Cfg, int NG>
+template <typename Cfg, int NG, int WAVES>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
                         SamplingLayout lay, int B, int S, int M, float *out)
 {
+    // dynamic LDS: the larger of this kernel's window and the fallback body's
+    constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
+                                                                                   : TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG>, Cfg::THREADS,
-                                                         Cfg::LDS_BYTES) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES>, Cfg::THREADS,
+                                                         LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    hipLaunchKernelGGL((msda_fwd_group<Cfg, NG>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
+    hipLaunchKernelGGL((msda_fwd_group<Cfg, NG, WAVES>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
     return (int)hipGetLastError();
 }
 
@@ -274,10 +287,10 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out)
 {
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out
-    if (D == 16 && L == 7) return launch_group<GCfg16, 7>(GROUP_ARGS);
-    if (D == 16 && L == 6) return launch_group<GCfg16, 6>(GROUP_ARGS);
-    if (D == 32 && L == 7) return launch_group<GCfg32, 7>(GROUP_ARGS);
-    if (D == 32 && L == 6) return launch_group<GCfg32, 6>(GROUP_ARGS);
+    if (D == 16 && L == 7) return launch_group<GWide16, 7, 2>(GROUP_ARGS);
+    if (D == 16 && L == 6) return launch_group<GWide16, 6, 2>(GROUP_ARGS);
+    if (D == 32 && L == 7) return launch_group<GWide32, 7, 2>(GROUP_ARGS);
+    if (D == 32 && L == 6) return launch_group<GWide32, 6, 2>(GROUP_ARGS);
     return (int)hipErrorInvalidValue;
 }
 

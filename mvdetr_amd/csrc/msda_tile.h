@@ -34,6 +34,13 @@ template <int D_, int SLICE_, int TH_, int TW_, int R_, int THREADS_ = TH_ * TW_
     static_assert(ROWS_PER_PASS >= 1, "window copy: one pass must cover at least one row");
 };
 
+// 128-byte slices: 71.7 KB window, 2 workgroups / CU.  64-byte slices: 35.8 KB, 4 workgroups / CU (twice the
+// waves to hide LDS and global latency behind, at the price of duplicating the per-tap address math).
+using CfgWide16 = TileCfg<16, 32, 8, 16, 6>;
+using CfgWide32 = TileCfg<32, 32, 8, 16, 6>;
+using CfgNarrow16 = TileCfg<16, 16, 8, 16, 6>;
+using CfgNarrow32 = TileCfg<32, 16, 8, 16, 6>;
+
 // Where element (query, head, level) of the sampling locations / weights starts: query * q + head * h +
 // level * l floats.  Covers the reference layout [.., Lq, M, L, P(, 2)] and the fused path's level-major and
 // column-block layouts; filled in by the host.
