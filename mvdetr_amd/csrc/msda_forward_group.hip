@@ -8,7 +8,8 @@
 // and barriers drop by L, the taps per barrier rise by L.  That needs the sampling data of (camera, level)
 // when level's window is resident, which the reference layout [Lq, M, L, P] scatters over the tensor; the
 // fused path's level-major raw layout [Lq, L, M, P] (a row permutation of the module's Linear) makes it one
-// contiguous run per query -- so this kernel exists for the FUSED entry point only.
+// contiguous run per query -- that is where this kernel pays (170 -> 128 us); on the reference layout it is
+// only marginally ahead of the tile kernel (188 vs 197 us).
 //
 // Lane = (cell, half slice) as in the tile kernel, but with NG accumulator sets (one per camera) and NG
 // online-softmax states.  The window copy is synchronous (its latency is now amortised over NG x 4 taps),
@@ -32,7 +33,9 @@ __device__ __forceinline__ void gfma4(float2v &lo, float2v &hi, float w, const f
     hi = __builtin_elementwise_fma(ww, (float2v){c.z, c.w}, hi);
 }
 
-template <typename Cfg, int NG, int WAVES>
+// FUSED = false: `off` / `logit` hold final sampling locations / attention weights (the extension's public
+// contract, any SamplingLayout) and `ref` is unused.
+template <typename Cfg, int NG, int WAVES, bool FUSED>
 __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         if (shapes[2 * l] != shapes[0] || shapes[2 * l + 1] != shapes[1]) {            // not ours (see header)
             using Fallback = TileCfg<Cfg::D, 32, 8, 16, 6>;
             static_assert(Fallback::THREADS == Cfg::THREADS, "the fallback body runs on this launch's workgroups");
-            msda_fwd_tile_body<Fallback, true>(win, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, L, out);
+            msda_fwd_tile_body<Fallback, FUSED>(win, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, L, out);
             return;
         }
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         const int64_t cell = active ? (int64_t)qy * Wq + qx : 0;
         const float *lp0 = off + cell * lay.q_l + head * lay.h_l;
         const float *wp0 = logit + cell * lay.q_w + head * lay.h_w;
-        const float *rp0 = ref + b * ref_bstride + cell * L * P * 2;
+        const float *rp0 = FUSED ? ref + b * ref_bstride + cell * L * P * 2 : nullptr;
         auto cam_q = [&](int c) { return (int64_t)b * S + lsi[c]; };          // wave-uniform
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
 
@@ -129,16 +132,18 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
             if (active) {
                 // sampling data of (camera, level): raw offsets (2 x float4), raw logits, reference points;
                 // camera c+1's loads are in flight while camera c's taps run
-                float4 na, nb, nw, nra, nrb;
+                float4 na, nb, nw, nra = make_float4(0, 0, 0, 0), nrb = nra;
                 auto load_cam = [&](int c) {
                     const int64_t cq = cam_q(c);
                     const float *lp = lp0 + cq * lay.q_l + l * lay.l_l;
                     na = *reinterpret_cast<const float4 *>(lp);
                     nb = *reinterpret_cast<const float4 *>(lp + 4);
                     nw = *reinterpret_cast<const float4 *>(wp0 + cq * lay.q_w + l * lay.l_w);
-                    const float *rp = rp0 + (cq - (int64_t)b * S) * L * P * 2 + l * P * 2;
-                    nra = *reinterpret_cast<const float4 *>(rp);
-                    nrb = *reinterpret_cast<const float4 *>(rp + 4);
+                    if constexpr (FUSED) {
+                        const float *rp = rp0 + (cq - (int64_t)b * S) * L * P * 2 + l * P * 2;
+                        nra = *reinterpret_cast<const float4 *>(rp);
+                        nrb = *reinterpret_cast<const float4 *>(rp + 4);
+                    }
                 };
                 load_cam(0);
 #pragma unroll
@@ -146,20 +151,28 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     float4 la = na, lb = nb, wa = nw;
                     const float4 ra = nra, rb = nrb;
                     if (c + 1 < NG) load_cam(c + 1);
-                    // fold this level's logits into camera c's running softmax
-                    const float m = fmaxf(smax[c], fmaxf(fmaxf(wa.x, wa.y), fmaxf(wa.z, wa.w)));
-                    const float sc = __expf(smax[c] - m);
-                    wa = make_float4(__expf(wa.x - m), __expf(wa.y - m), __expf(wa.z - m), __expf(wa.w - m));
-                    ssum[c] = ssum[c] * sc + (wa.x + wa.y) + (wa.z + wa.w);
-                    smax[c] = m;
-                    const float2v scv = {sc, sc};
+                    float xs[4], ys[4];
+                    if constexpr (FUSED) {
+                        // fold this level's logits into camera c's running softmax
+                        const float m = fmaxf(smax[c], fmaxf(fmaxf(wa.x, wa.y), fmaxf(wa.z, wa.w)));
+                        const float sc = __expf(smax[c] - m);
+                        wa = make_float4(__expf(wa.x - m), __expf(wa.y - m), __expf(wa.z - m), __expf(wa.w - m));
+                        ssum[c] = ssum[c] * sc + (wa.x + wa.y) + (wa.z + wa.w);
+                        smax[c] = m;
+                        const float2v scv = {sc, sc};
 #pragma unroll
-                    for (int i = 0; i < 2 * NV; ++i) acc[c][i] *= scv;
-                    // pixel coordinates: (ref + off / size) * size - 0.5
-                    const float xs[4] = {(ra.x + la.x * iw) * fW - 0.5f, (ra.z + la.z * iw) * fW - 0.5f,
-                                         (rb.x + lb.x * iw) * fW - 0.5f, (rb.z + lb.z * iw) * fW - 0.5f};
-                    const float ys[4] = {(ra.y + la.y * ih) * fH - 0.5f, (ra.w + la.w * ih) * fH - 0.5f,
-                                         (rb.y + lb.y * ih) * fH - 0.5f, (rb.w + lb.w * ih) * fH - 0.5f};
+                        for (int i = 0; i < 2 * NV; ++i) acc[c][i] *= scv;
+                        // pixel coordinates: (ref + off / size) * size - 0.5
+                        xs[0] = (ra.x + la.x * iw) * fW - 0.5f; ys[0] = (ra.y + la.y * ih) * fH - 0.5f;
+                        xs[1] = (ra.z + la.z * iw) * fW - 0.5f; ys[1] = (ra.w + la.w * ih) * fH - 0.5f;
+                        xs[2] = (rb.x + lb.x * iw) * fW - 0.5f; ys[2] = (rb.y + lb.y * ih) * fH - 0.5f;
+                        xs[3] = (rb.z + lb.z * iw) * fW - 0.5f; ys[3] = (rb.w + lb.w * ih) * fH - 0.5f;
+                    } else {
+                        xs[0] = la.x * fW - 0.5f; ys[0] = la.y * fH - 0.5f;
+                        xs[1] = la.z * fW - 0.5f; ys[1] = la.w * fH - 0.5f;
+                        xs[2] = lb.x * fW - 0.5f; ys[2] = lb.y * fH - 0.5f;
+                        xs[3] = lb.z * fW - 0.5f; ys[3] = lb.w * fH - 0.5f;
+                    }
                     const float aws[4] = {wa.x, wa.y, wa.z, wa.w};
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
@@ -201,7 +214,8 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
                 const int64_t cq = cam_q(c);
-                const float *lp = lp0 + cq * lay.q_l, *wp = wp0 + cq * lay.q_w, *rp = rp0 + lsi[c] * L * P * 2;
+                const float *lp = lp0 + cq * lay.q_l, *wp = wp0 + cq * lay.q_w;
+                const float *rp = FUSED ? rp0 + lsi[c] * L * P * 2 : nullptr;
                 unsigned mm = miss[c];
                 // taps that left the window: straight from global memory (zero padding by test)
                 while (mm) {
@@ -209,9 +223,13 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     mm &= mm - 1;
                     const int l = bit / P, pp = bit - l * P;
                     const float fW = (float)Wq, fH = (float)Hq;
-                    const float x = (rp[bit * 2 + 0] + lp[l * lay.l_l + pp * 2 + 0] * (1.f / fW)) * fW - 0.5f;
-                    const float y = (rp[bit * 2 + 1] + lp[l * lay.l_l + pp * 2 + 1] * (1.f / fH)) * fH - 0.5f;
-                    const float a = __expf(wp[l * lay.l_w + pp] - smax[c]);
+                    float lx = lp[l * lay.l_l + pp * 2 + 0], ly = lp[l * lay.l_l + pp * 2 + 1], a = wp[l * lay.l_w + pp];
+                    if constexpr (FUSED) {
+                        lx = rp[bit * 2 + 0] + lx * (1.f / fW);
+                        ly = rp[bit * 2 + 1] + ly * (1.f / fH);
+                        a = __expf(a - smax[c]);
+                    }
+                    const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
                     if (!(y > -1.f && x > -1.f && y < fH && x < fW)) continue;
                     const Footprint<float> f = footprint(y, x, Hq, Wq);
                     const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * Wq + f.x0) * row;
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                         gfma4(acc[c][2 * k], acc[c][2 * k + 1], w11, c11);
                     }
                 }
-                const float inv = 1.f / ssum[c];
+                const float inv = FUSED ? 1.f / ssum[c] : 1.f;
                 float *o = out + ((cq + cell) * M + head) * D + ch_off;
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
 using GWide16 = TileCfg<16, 32, 6, 16, 6, 256>;
 using GWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 
-template <typename Cfg, int NG, int WAVES>
+template <typename Cfg, int NG, int WAVES, bool FUSED>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
                         SamplingLayout lay, int B, int S, int M, float *out)
@@ -261,18 +279,18 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
     constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
                                                                                    : TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES>, Cfg::THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES, FUSED>, Cfg::THREADS,
                                                          LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    hipLaunchKernelGGL((msda_fwd_group<Cfg, NG, WAVES>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
+    hipLaunchKernelGGL((msda_fwd_group<Cfg, NG, WAVES, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
     return (int)hipGetLastError();
 }
 
@@ -287,10 +305,11 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out)
 {
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out
-    if (D == 16 && L == 7) return launch_group<GWide16, 7, 2>(GROUP_ARGS);
-    if (D == 16 && L == 6) return launch_group<GWide16, 6, 2>(GROUP_ARGS);
-    if (D == 32 && L == 7) return launch_group<GWide32, 7, 2>(GROUP_ARGS);
-    if (D == 32 && L == 6) return launch_group<GWide32, 6, 2>(GROUP_ARGS);
+    const bool fused = ref != nullptr;
+    if (D == 16 && L == 7) return fused ? launch_group<GWide16, 7, 2, true>(GROUP_ARGS) : launch_group<GWide16, 7, 2, false>(GROUP_ARGS);
+    if (D == 16 && L == 6) return fused ? launch_group<GWide16, 6, 2, true>(GROUP_ARGS) : launch_group<GWide16, 6, 2, false>(GROUP_ARGS);
+    if (D == 32 && L == 7) return fused ? launch_group<GWide32, 7, 2, true>(GROUP_ARGS) : launch_group<GWide32, 7, 2, false>(GROUP_ARGS);
+    if (D == 32 && L == 6) return fused ? launch_group<GWide32, 6, 2, true>(GROUP_ARGS) : launch_group<GWide32, 6, 2, false>(GROUP_ARGS);
     return (int)hipErrorInvalidValue;
 }
 

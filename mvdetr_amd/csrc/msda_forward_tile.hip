@@ -98,6 +98,10 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
                       int P, float *out)
 {
     const SamplingLayout lay = {M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P};     // [.., Lq, M, L, P(, 2)]
+    // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
+    // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
+    if (msda_group_supported(D, L) && !narrow_slices())
+        return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, B, S, M, D, L, out);
     return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, B, S, M, D, L, out);
 }
 
