@@ -23,7 +23,10 @@ Prints ONE JSON line (rank 0):
 
 Multi-GPU: `--parallel dp` (default) runs one independent frame per rank -- frames shard with no
 data-path collective, weak scaling; `--parallel views` partitions the cameras of ONE frame over the
-ranks with a single RCCL all-gather of per-view world tokens before the shadow transformer.
+ranks: trunk, warp and token conv per view, then `--encoder sharded` (default; each rank runs the shadow
+transformer on its own cameras' queries, all-gathering the projected values once per layer and all-reducing
+the merge convolution's partial sums) or `--encoder replicated` (one all-gather of per-view world tokens, then
+every rank runs the whole encoder).  RCCL over xGMI either way; scaling "strong" (one frame).
 """
 from __future__ import annotations
 
@@ -50,6 +53,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="wildtrack", choices=["wildtrack", "multiviewx", "stress16"])
     ap.add_argument("--parallel", default="dp", choices=["dp", "views"])
+    ap.add_argument("--encoder", default="sharded", choices=["sharded", "replicated"],
+                    help="--parallel views only: shadow transformer partitioned by camera, or replicated")
     ap.add_argument("--batch", type=int, default=1, help="frames per step per rank (dp mode; the reference only supports 1)")
     ap.add_argument("--augment", action="store_true", help="random affine augmentation matrices instead of identity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,7 +179,7 @@ def main():
     M = geometry.random_affine_mats(Bf, N, (Hi, Wi), seed=rank) if a.augment else torch.eye(3).repeat(Bf, N, 1, 1)
 
     if a.parallel == "views" and world > 1:
-        runner = mdist.ViewShardedFrame(model)
+        runner = mdist.ViewShardedFrame(model, encoder=a.encoder)
         s, e = runner.range
         imgs = torch.randn(1, max(e - s, 0), 3, Hi, Wi, generator=torch.Generator().manual_seed(1000)).to(dev) \
             if e > s else torch.zeros(1, 0, 3, Hi, Wi, device=dev)
@@ -236,7 +241,7 @@ def main():
         "config": {"workload": f"{a.config} {N}-cam frame, --world_feat deform_trans, ResNet18 trunk: "
                                f"{N}x3x{Hi}x{Wi} -> {geom.feat_channels}-ch world feat {geom.Rworld_shape[0]}x{geom.Rworld_shape[1]} "
                                f"-> BEV (BASELINE.json configs[1])" if a.config == "wildtrack" else f"{a.config} {N}-cam frame",
-                   "frames_per_step": frames_per_step, "batch_per_rank": Bf, "parallelism": f"{a.parallel}{world}",
+                   "frames_per_step": frames_per_step, "batch_per_rank": Bf, "parallelism": f"{a.parallel}{world}" + (f"-{a.encoder}" if a.parallel == "views" and world > 1 else ""),
                    "augment": bool(a.augment),
                    "weights": "seeded random"},
         "roofline": {"bound": "hbm", "kernel": f"msda_forward[{impl}]", "achieved": round(achieved, 1) if achieved else None,

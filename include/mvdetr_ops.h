@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 2
+#define MVDETR_OPS_ABI_VERSION 3
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -74,6 +74,21 @@ int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_
                                   const float *attn_logits, int level_major, int offsets_query_stride,
                                   int logits_query_stride, int batch, int spatial_size, int num_heads,
                                   int channels, int num_levels, int num_query, int num_point, float *out);
+
+/* The same with the queries restricted to the tokens of levels [query_level_begin, query_level_end): the
+ * encoder call of ONE rank of a query-sharded run (cameras = levels partitioned over GPUs; SURVEY 8e option
+ * B -- not in the reference, which is single-device).  `value` still holds all spatial_size tokens;
+ * reference_points, sampling_offsets, attn_logits and out hold only the num_query =
+ * sum_{l in range} H_l*W_l queries of the range, in token order.  (0, num_levels) is the call above. */
+int mvdetr_msda_fused_levels_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                       int num_query, int num_point, int query_level_begin, int query_level_end);
+int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start_index, const float *reference_points,
+                                         int64_t ref_batch_stride, const float *sampling_offsets,
+                                         const float *attn_logits, int level_major, int offsets_query_stride,
+                                         int logits_query_stride, int query_level_begin, int query_level_end,
+                                         int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                         int num_query, int num_point, float *out);
 
 /* ---- Multi-scale deformable attention, backward -----------------------------------------------
  * Replaces ms_deformable_col2im_cuda (ms_deform_im2col_cuda.cuh:956-1327) and its six kernel

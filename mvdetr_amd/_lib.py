@@ -15,13 +15,14 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
 _MSDA_BWD = [_vp] * 7 + [_i] * 7 + [_vp] * 3
 _WARP = [_vp] * 3 + [_i] * 7 + [_vp]
 _MSDA_FUSED = [_vp] * 5 + [ctypes.c_int64] + [_vp] * 2 + [_i] * 10 + [_vp]
+_MSDA_FUSED_LEVELS = [_vp] * 5 + [ctypes.c_int64] + [_vp] * 2 + [_i] * 12 + [_vp]
 
 SIGNATURES = {
     "mvdetr_ops_abi_version": ([], _i),
@@ -31,6 +32,8 @@ SIGNATURES = {
     "mvdetr_msda_forward_f64": (_MSDA_FWD, _i),
     "mvdetr_msda_fused_supported": ([_i] * 7, _i),
     "mvdetr_msda_forward_fused_f32": (_MSDA_FUSED, _i),
+    "mvdetr_msda_fused_levels_supported": ([_i] * 9, _i),
+    "mvdetr_msda_forward_fused_levels_f32": (_MSDA_FUSED_LEVELS, _i),
     "mvdetr_msda_backward_f32": (_MSDA_BWD, _i),
     "mvdetr_msda_backward_f64": (_MSDA_BWD, _i),
     "mvdetr_warp_perspective_forward_f32": (_WARP, _i),

@@ -23,13 +23,14 @@ inline int msda_forward_tile(hipStream_t, const double *, const int64_t *, const
 // mvdetr_msda_set_forward_impl().
 int msda_fwd_impl_knob();
 
-bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16);
+// queries = tokens of levels [ql0, ql1) (0, L: all, the plain encoder call, which needs Lq == S)
+bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16, int ql0, int ql1);
 
 // fused variant: reference points + raw offsets + raw logits (see msda_forward_tile.hip)
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
-                            int level_major, int qstride_l, int qstride_w, int B, int S, int M, int D, int L,
-                            float *out);
+                            int level_major, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
+                            int M, int D, int L, float *out);
 
 template <typename T>
 inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *aw, const T *out, int B,
@@ -40,7 +41,7 @@ inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *a
     if (env == 1) return MsdaFwdImpl::Gather;
     const bool a16 = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(loc) |
                        reinterpret_cast<uintptr_t>(aw) | reinterpret_cast<uintptr_t>(out)) % 16) == 0;
-    if (!msda_tile_supported(B, S, M, D, L, Lq, P, a16)) return MsdaFwdImpl::Gather;
+    if (!msda_tile_supported(B, S, M, D, L, Lq, P, a16, 0, L)) return MsdaFwdImpl::Gather;
     return MsdaFwdImpl::Tile;
 }
 

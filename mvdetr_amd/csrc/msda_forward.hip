@@ -164,8 +164,15 @@ int mvdetr_msda_set_forward_impl(int impl)
 int mvdetr_msda_fused_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels,
                                 int num_query, int num_point)
 {
-    return mvdetr::msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, true)
-               ? 1 : 0;
+    return mvdetr_msda_fused_levels_supported(batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                              num_point, 0, num_levels);
+}
+
+int mvdetr_msda_fused_levels_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                       int num_query, int num_point, int query_level_begin, int query_level_end)
+{
+    return mvdetr::msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, true,
+                                       query_level_begin, query_level_end) ? 1 : 0;
 }
 
 int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_t *spatial_shapes,
@@ -175,6 +182,21 @@ int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_
                                   int logits_query_stride, int batch, int spatial_size, int num_heads,
                                   int channels, int num_levels, int num_query, int num_point, float *out)
 {
+    return mvdetr_msda_forward_fused_levels_f32(stream, value, spatial_shapes, level_start_index, reference_points,
+                                                ref_batch_stride, sampling_offsets, attn_logits, level_major,
+                                                offsets_query_stride, logits_query_stride, 0, num_levels, batch,
+                                                spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                                out);
+}
+
+int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start_index, const float *reference_points,
+                                         int64_t ref_batch_stride, const float *sampling_offsets,
+                                         const float *attn_logits, int level_major, int offsets_query_stride,
+                                         int logits_query_stride, int query_level_begin, int query_level_end,
+                                         int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                         int num_query, int num_point, float *out)
+{
     using namespace mvdetr;
     const int dense_l = num_heads * num_levels * num_point * 2, dense_w = num_heads * num_levels * num_point;
     if (offsets_query_stride == 0) offsets_query_stride = dense_l;
@@ -183,18 +205,22 @@ int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_
         return (int)hipErrorInvalidValue;
     if (bad_dims(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point))
         return (int)hipErrorInvalidValue;
+    if (query_level_begin < 0 || query_level_end <= query_level_begin || query_level_end > num_levels)
+        return (int)hipErrorInvalidValue;
     if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !out)
         return (int)hipErrorInvalidValue;
     const bool a16 = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(reference_points) |
                        reinterpret_cast<uintptr_t>(sampling_offsets) | reinterpret_cast<uintptr_t>(attn_logits) |
                        reinterpret_cast<uintptr_t>(out)) % 16) == 0 && ref_batch_stride % 4 == 0;
-    if (!msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, a16))
+    if (!msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, a16,
+                             query_level_begin, query_level_end))
         return (int)hipErrorNotSupported;
     g_last_impl = "tile_fused";
     return msda_forward_tile_fused(reinterpret_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
                                    reference_points, ref_batch_stride, sampling_offsets, attn_logits,
-                                   level_major ? 1 : 0, offsets_query_stride, logits_query_stride, batch, spatial_size,
-                                   num_heads, channels, num_levels, out);
+                                   level_major ? 1 : 0, offsets_query_stride, logits_query_stride, query_level_begin,
+                                   query_level_end, num_query, batch, spatial_size, num_heads, channels, num_levels,
+                                   out);
 }
 
 int mvdetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,

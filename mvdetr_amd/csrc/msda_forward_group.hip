@@ -54,7 +54,8 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         if (shapes[2 * l] != shapes[0] || shapes[2 * l + 1] != shapes[1]) {            // not ours (see header)
             using Fallback = TileCfg<Cfg::D, 32, 8, 16, 6>;
             static_assert(Fallback::THREADS == Cfg::THREADS, "the fallback body runs on this launch's workgroups");
-            msda_fwd_tile_body<Fallback, FUSED>(win, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, L, out);
+            msda_fwd_tile_body<Fallback, FUSED>(win, value, shapes, lsi, off, logit, ref, ref_bstride, lay,
+                                                QueryLevels{0, L, S}, B, S, M, L, out);
             return;
         }
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];

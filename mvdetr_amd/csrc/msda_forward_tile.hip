@@ -35,23 +35,25 @@ template <typename Cfg, bool FUSED>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
-    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M, int L,
-    float *__restrict__ out)
+    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, QueryLevels qr, int B, int S, int M,
+    int L, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
-    msda_fwd_tile_body<Cfg, FUSED>(win, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, B, S, M, L, out);
+    msda_fwd_tile_body<Cfg, FUSED>(win, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out);
 }
 
-bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16)
+bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16, int ql0, int ql1)
 {
-    if (!aligned16 || P != TILE_P || L > TILE_MAX_LEVELS || Lq != S || B < 1) return false;
+    if (!aligned16 || P != TILE_P || L > TILE_MAX_LEVELS || B < 1) return false;
+    const bool all_levels = ql0 == 0 && ql1 == L;
+    if (ql0 < 0 || ql1 <= ql0 || ql1 > L || (all_levels ? Lq != S : Lq > S)) return false;
     return (D == 16 && M % 2 == 0) || D == 32;
 }
 
 template <typename Cfg, bool FUSED>
 static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
-                       int B, int S, int M, int L, float *out)
+                       QueryLevels qr, int B, int S, int M, int L, float *out)
 {
     static int blocks = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>),
@@ -67,7 +69,7 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
     }();
     hipLaunchKernelGGL((msda_fwd_tile<Cfg, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
-                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, B, S, M, L, out);
+                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out);
     return (int)hipGetLastError();
 }
 
@@ -80,12 +82,12 @@ static bool narrow_slices()
     return v;
 }
 
-#define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, B, S, M, L, out
+#define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out
 
 template <bool FUSED>
 static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
-                         int B, int S, int M, int D, int L, float *out)
+                         QueryLevels qr, int B, int S, int M, int D, int L, float *out)
 {
     const bool narrow = narrow_slices();
     if (D == 16) return narrow ? launch_tile<CfgNarrow16, FUSED>(TILE_ARGS) : launch_tile<CfgWide16, FUSED>(TILE_ARGS);
@@ -102,13 +104,13 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
     if (msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, B, S, M, D, L, out);
-    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, B, S, M, D, L, out);
+    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out);
 }
 
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
-                            int level_major, int qstride_l, int qstride_w, int B, int S, int M, int D, int L,
-                            float *out)
+                            int level_major, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
+                            int M, int D, int L, float *out)
 {
     const int P = TILE_P;
     const SamplingLayout lay = level_major
@@ -116,9 +118,13 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
         : SamplingLayout{qstride_l, L * P * 2, P * 2, qstride_w, L * P, P};             // [.., Lq, M, L, P(, 2)]
     // MVDeTr's camera counts: the camera-grouped kernel (which falls back to this file's tile body, in the
     // same launch, when the levels turn out on the device to have unequal shapes) -- msda_forward_group.hip
-    if (msda_group_supported(D, L) && !narrow_slices())
+    // A query-sharded call (a rank's own cameras as queries, mvdetr_amd/dist.py) has too few query levels per
+    // window to amortise the grouped staging and runs the tile kernel.
+    const bool all_levels = ql0 == 0 && ql1 == L;
+    if (all_levels && msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay, B, S, M, D, L, out);
-    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay, B, S, M, D, L, out);
+    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
+                               QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out);
 }
 
 }  // namespace mvdetr

@@ -49,6 +49,11 @@ struct SamplingLayout {
     int q_w, h_w, l_w;      // weights (or raw logits)
 };
 
+// Which levels' tokens are the queries of a call: [begin, end) of the L levels, Lq tokens in all.
+struct QueryLevels {
+    int begin, end, Lq;
+};
+
 // camera-grouped fused forward (msda_forward_group.hip)
 bool msda_group_supported(int D, int L);
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,

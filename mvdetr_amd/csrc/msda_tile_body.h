@@ -36,7 +36,7 @@ template <typename Cfg, bool FUSED>
 __device__ __forceinline__ void msda_fwd_tile_body(float *win,
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
-    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S,
+    const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, QueryLevels qr, int B, int S,
     int M, int L, float *__restrict__ out)
 {
     constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
@@ -46,17 +46,23 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
     const int row = M * D;                                // floats per value token
 
     // ---- the tile list: [level][tile-in-level] x head slice x batch ------------------------------
+    // The queries are the tokens of levels [qr.begin, qr.end) -- all L levels for the plain encoder call, one
+    // rank's cameras for the query-sharded encoder (mvdetr_amd/dist.py); `loc`, `aw`, `ref` and `out` hold
+    // exactly those qr.Lq queries, in token order.  The value tokens are always those of all L levels.
+    const int NQ = qr.end - qr.begin;
+    const int64_t q_first = lsi[qr.begin];
+    const int Lq = qr.Lq;
     int tiles_spatial = 0;
     bool equal_shapes = true;
     for (int l = 0; l < L; ++l) {
-        tiles_spatial += tiles_of_level<Cfg>(shapes, l);
+        if (l >= qr.begin && l < qr.end) tiles_spatial += tiles_of_level<Cfg>(shapes, l);
         equal_shapes = equal_shapes && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
     }
-    const int per_level = equal_shapes ? tiles_spatial / L : 0;
+    const int per_level = equal_shapes ? tiles_spatial / NQ : 0;
     const int units = per_level * HS * B;                 // (tile, slice, batch) units, equal shapes only
     const int units8 = (units + 7) / 8;                   // units per XCD
-    // equal shapes: t enumerates xcd x (unit of that xcd) x level, see the decode below
-    const int total = equal_shapes ? units8 * 8 * L : tiles_spatial * HS * B;
+    // equal shapes: t enumerates xcd x (unit of that xcd) x query level, see the decode below
+    const int total = equal_shapes ? units8 * 8 * NQ : tiles_spatial * HS * B;
 
     const int sub = tid & 1;                              // which half of the slice this lane owns
     const int qi = tid >> 1;
@@ -79,9 +85,9 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
             // units, and run the L query levels of one unit back to back: their source windows are
             // identical, so all but the first find them in that L2.
             const int xcd = t & 7, r = t >> 3;
-            lq = r % L;
-            const int unit = xcd * units8 + r / L;
-            if (r / L >= units8 || unit >= units) continue;
+            lq = qr.begin + r % NQ;
+            const int unit = xcd * units8 + r / NQ;
+            if (r / NQ >= units8 || unit >= units) continue;
             hs = unit % HS;
             const int u2 = unit / HS;
             tin = u2 % per_level;
@@ -91,7 +97,7 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
             const int u2 = t / HS;
             b = u2 / tiles_spatial;
             int rem = u2 % tiles_spatial;
-            lq = 0;
+            lq = qr.begin;
             for (;; ++lq) {
                 const int n = tiles_of_level<Cfg>(shapes, lq);
                 if (rem < n) break;
@@ -106,15 +112,17 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
         const int head = ch0 / D, ch_off = ch0 % D;
 
         const int qy = Y0 + qly, qx = X0 + qlx;
-        const bool active = qy < Hq && qx < Wq;
-        const int64_t q = lsi[lq] + (int64_t)qy * Wq + qx;          // query index == token index
-        const int64_t bqm = active ? (((int64_t)b * S + q) * M + head) : 0;
+        // query index: token index minus the first token of the query levels (guarded against a caller whose
+        // Lq is smaller than the levels it names)
+        const int64_t q = lsi[lq] - q_first + (int64_t)qy * Wq + qx;
+        const bool active = qy < Hq && qx < Wq && q < Lq;
+        const int64_t bqm = active ? (((int64_t)b * Lq + q) * M + head) : 0;
         // sampling data of this (query, head): element (query, head, level) of `loc` starts at
         // query * lay.q_l + head * lay.h_l + level * lay.l_l floats (`aw`: the *_w strides).  The reference
         // layout [.., Lq, M, L, P(, 2)] and the level-major / column-block layouts of the fused path are all
         // instances of it; the host fills the strides in.
         const int lstep_l = lay.l_l, lstep_w = lay.l_w;
-        const int64_t bq = active ? (int64_t)b * S + q : 0;
+        const int64_t bq = active ? (int64_t)b * Lq + q : 0;
         const float *lp = loc + bq * lay.q_l + head * lay.h_l;
         const float *wp = aw + bq * lay.q_w + head * lay.h_w;
         const float *rp = FUSED ? ref + b * ref_bstride + (active ? q : 0) * L * P * 2 : nullptr;

@@ -9,7 +9,15 @@ Two ways the path shards:
     token conv run per view; every rank then needs the tokens of ALL views as attention `value`
     -> exactly ONE all-gather of per-view world tokens per frame ("views").  The payload per view is
     h*w*C fp32 = 5.5 MB at Wildtrack size; over fully connected xGMI RCCL uses a direct exchange for
-    that size.  The encoder is replicated after the gather.
+    that size.  The encoder is then either replicated (ViewShardedFrame(encoder="replicated")) or
+  * query-sharded (SURVEY 8e option B / 8f row f3, the default): every MSDeformAttn query is independent and
+    only `value` must be complete, so each rank keeps running ONLY its own cameras' tokens through the three
+    encoder layers.  Per layer it projects its own tokens (value_proj), all-gathers the projected values
+    (the same 5.5 MB per view -- this replaces the token all-gather above, which is no longer needed), and
+    runs attention (fused kernel restricted to its query levels), norm and FFN on its own queries.  The
+    per-camera 1x1 merge convolution (trans_world_feat.py:82,107-108) is a sum over cameras: each rank
+    applies its cameras' weight columns and ONE all-reduce of the [C, h, w] partial sums finishes it.
+    Collectives per frame: 3 all-gathers + 1 all-reduce; no rank ever touches another camera's queries.
 """
 from __future__ import annotations
 
@@ -49,7 +57,7 @@ def partition_views(num_views: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=None) -> torch.Tensor:
+def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=None, hw: int = None) -> torch.Tensor:
     """local_tokens [B, n_local*hw, C] (this rank's views, possibly none) -> [B, num_views*hw, C] on
     every rank, views in camera order.  One all_gather_into_tensor; ragged shards are padded to the
     largest shard and the padding is dropped after the collective.  Inference only: the collective is
@@ -62,12 +70,14 @@ def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=Non
     B, _, C = local_tokens.shape
     n_max = max(e - s for s, e in parts)
     n_loc = parts[rank][1] - parts[rank][0]
-    hw = local_tokens.shape[1] // n_loc if n_loc else None
-    # every rank must agree on hw; ranks without a view learn it from the others via a tiny all-reduce
-    hw_t = torch.tensor([hw or 0], device=local_tokens.device, dtype=torch.int64)
-    if any(e == s for s, e in parts):
-        dist.all_reduce(hw_t, op=dist.ReduceOp.MAX, group=group)
-    hw = int(hw_t.item())
+    if hw is None:
+        hw = local_tokens.shape[1] // n_loc if n_loc else None
+        # every rank must agree on hw (tokens per view); ranks without a view learn it from the others via a
+        # tiny all-reduce -- callers that know it pass `hw` and skip this host synchronisation
+        hw_t = torch.tensor([hw or 0], device=local_tokens.device, dtype=torch.int64)
+        if any(e == s for s, e in parts):
+            dist.all_reduce(hw_t, op=dist.ReduceOp.MAX, group=group)
+        hw = int(hw_t.item())
     with torch.no_grad():
         send = local_tokens.new_zeros(B, n_max * hw, C)
         if n_loc:
@@ -80,14 +90,78 @@ def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=Non
     return torch.cat(pieces, dim=1)
 
 
-class ViewShardedFrame:
-    """Runs one frame with the cameras partitioned over the ranks of `group`."""
+class QueryShardedFusion:
+    """DeformTransWorldFeat.fuse() with the encoder's queries partitioned by camera over `world` ranks.
 
-    def __init__(self, model, group=None):
+    Written as the per-rank steps (layer_value / layer_update / merge_partial / merge_finish) plus
+    __call__, which strings them together with the collectives -- so a test can drive several emulated ranks
+    in lock-step on one device and compare with the unsharded fuse()."""
+
+    def __init__(self, world_feat, rank: int, world: int, group=None):
+        self.wf, self.rank, self.world, self.group = world_feat, rank, world, group
+        self.views = partition_views(world_feat.num_cam, world)[rank]
+
+    def own_slice(self, h, w):
+        s, e = self.views
+        return slice(s * h * w, e * h * w)
+
+    def layer_value(self, i, src_own):
+        """This rank's share of layer i's `value`: value_proj of its own tokens, [B, n_own*h*w, C]."""
+        return self.wf.encoder.layers[i].self_attn.project_value(src_own)
+
+    def layer_update(self, i, src_own, value_all, h, w):
+        """Encoder layer i on this rank's queries, given the projected values of ALL cameras."""
+        s, e = self.views
+        if e == s:
+            return src_own
+        wf, own = self.wf, self.own_slice(h, w)
+        B = src_own.shape[0]
+        ref = wf.encoder.reference_points[own].unsqueeze(0).expand(B, -1, -1, -1, -1)
+        return wf.encoder.layers[i](src_own, wf.level_pos(h, w)[:, own], ref, wf.spatial_shapes,
+                                    wf.level_start_index, query_levels=(s, e), projected_value=value_all)
+
+    def merge_partial(self, src_own, B, h, w):
+        """This rank's cameras' term of merge_linear's 1x1 convolution (no bias), [B, C, h, w]."""
+        wf, (s, e), C = self.wf, self.views, self.wf.hidden_dim
+        conv = wf.merge_linear[0]
+        if e == s:
+            return conv.weight.new_zeros(B, C, h, w)
+        x = src_own.view(B, e - s, h, w, C).permute(0, 1, 4, 2, 3).reshape(B, (e - s) * C, h, w)
+        return torch.nn.functional.conv2d(x, conv.weight[:, s * C:e * C])
+
+    def merge_finish(self, partial_sum):
+        wf = self.wf
+        y = partial_sum + wf.merge_linear[0].bias.view(1, -1, 1, 1)
+        return wf.upsample(wf.merge_linear[1](y))
+
+    @torch.no_grad()
+    def __call__(self, local_tokens, B, h, w):
+        """local_tokens [B, n_own*h*w, C] -> merged BEV feature [B, C, H, W], identical on every rank (up to
+        the summation order of the all-reduce)."""
+        src = local_tokens
+        for i in range(self.wf.encoder.num_layers):
+            value = all_gather_view_tokens(self.layer_value(i, src), self.wf.num_cam, self.group, hw=h * w)
+            src = self.layer_update(i, src, value, h, w)
+        part = self.merge_partial(src, B, h, w).contiguous()
+        if self.world > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        return self.merge_finish(part)
+
+
+class ViewShardedFrame:
+    """Runs one frame with the cameras partitioned over the ranks of `group`.  encoder="sharded": the shadow
+    transformer stays partitioned by camera (QueryShardedFusion); "replicated": one token all-gather, then
+    every rank runs the whole encoder."""
+
+    def __init__(self, model, group=None, encoder="sharded"):
         self.model, self.group = model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.range = partition_views(model.num_cam, self.world)[self.rank]
+        if encoder not in ("sharded", "replicated"):
+            raise ValueError(f"encoder must be 'sharded' or 'replicated', got {encoder!r}")
+        self.sharded = QueryShardedFusion(model.world_feat, self.rank, self.world, group) \
+            if encoder == "sharded" else None
 
     @torch.no_grad()
     def __call__(self, imgs_local, M):
@@ -108,8 +182,13 @@ class ViewShardedFrame:
         else:
             dev = next(m.parameters()).device
             local = torch.zeros(B, 0, wf.hidden_dim, device=dev)
-        tokens = all_gather_view_tokens(local, m.num_cam, self.group)
-        fused = wf.fuse(tokens, B, h, w)
+        if self.sharded is not None:
+            if e == s:                                     # idle rank: learn the token grid from the model
+                h, w = wf.pos_embedding.shape[-2:]
+            fused = self.sharded(local, B, h, w)
+        else:
+            tokens = all_gather_view_tokens(local, m.num_cam, self.group)
+            fused = wf.fuse(tokens, B, h, w)
         return m.world_heatmap(fused), m.world_offset(fused)
 
 

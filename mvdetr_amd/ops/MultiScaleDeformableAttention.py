@@ -90,21 +90,24 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [grad_value, grad_loc, grad_aw]
 
 
-def fused_supported(value, num_levels, num_query, num_point) -> bool:
+def fused_supported(value, num_levels, num_query, num_point, query_levels=None) -> bool:
     """True when ms_deform_attn_forward_fused takes this call (deformable-encoder shapes, fp32)."""
     if not value.is_cuda or value.dtype != torch.float32:
         return False
     B, S, M, D = value.shape
-    return bool(_lib.lib().mvdetr_msda_fused_supported(B, S, M, D, num_levels, num_query, num_point))
+    l0, l1 = (0, num_levels) if query_levels is None else query_levels
+    return bool(_lib.lib().mvdetr_msda_fused_levels_supported(B, S, M, D, num_levels, num_query, num_point, l0, l1))
 
 
 def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                                 attn_logits, level_major=False):
+                                 attn_logits, level_major=False, query_levels=None):
     """Core + the module arithmetic around it (ms_deform_attn.py:100-107) in one kernel (inference):
     value [B,S,M,D]; reference_points [B or 1, Lq, L, P, 2] (may be a batch-expanded view);
     sampling_offsets [B,Lq,M,L,P,2] and attn_logits [B,Lq,M,L,P] are the raw Linear outputs
     ([B,Lq,L,M,P,2] / [B,Lq,L,M,P] with ``level_major``); each may be a column block of a wider GEMM
     output (dense per query, arbitrary query stride).  -> [B, Lq, M*D].
+    ``query_levels=(l0, l1)``: the Lq queries are the tokens of levels l0..l1-1 only (one rank's cameras in a
+    query-sharded encoder, mvdetr_amd/dist.py); value still holds every level.
     No extension counterpart in the reference: this is SURVEY row f1."""
     _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index)])
     B, S, M, D = value.shape
@@ -120,7 +123,7 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
             # accept a column block [..., a:b] of a [B, Lq, K] GEMM output, viewed as [B, Lq, ., ., .(, 2)]
             st = t.stride()
             dense_inner = all(st[i] == st[i + 1] * t.shape[i + 1] for i in range(2, t.dim() - 1)) and st[-1] == 1
-            if not dense_inner or st[0] != st[1] * Lq:
+            if not dense_inner or (B > 1 and st[0] != st[1] * Lq):
                 raise RuntimeError(f"{name} tensor has to be contiguous per query")
         qstrides.append(t.stride(1))
     if reference_points.shape[-4:] != (Lq, L, P, 2) or not reference_points.is_cuda:
@@ -129,13 +132,14 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
         reference_points = reference_points.contiguous()
     rstride = reference_points.stride(0) if reference_points.shape[0] > 1 else 0
     _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)
+    l0, l1 = (0, L) if query_levels is None else (int(query_levels[0]), int(query_levels[1]))
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
-        rc = _lib.lib().mvdetr_msda_forward_fused_f32(
+        rc = _lib.lib().mvdetr_msda_forward_fused_levels_f32(
             _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), reference_points.data_ptr(), rstride, sampling_offsets.data_ptr(),
-            attn_logits.data_ptr(), 1 if level_major else 0, qstrides[0], qstrides[1], B, S, M, D, L, Lq, P,
-            out.data_ptr())
+            attn_logits.data_ptr(), 1 if level_major else 0, qstrides[0], qstrides[1], l0, l1, B, S, M, D, L, Lq,
+            P, out.data_ptr())
     _lib.check(rc, "ms_deform_attn_forward_fused")
     return out
 

@@ -42,6 +42,7 @@ class MSDeformAttn(nn.Module):
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
         self._validated = None
+        self._validated_q = None
         # inference calls of deformable-encoder shape run softmax + location arithmetic inside the kernel
         self.fused_inference = True
         self._fused_cache = None
@@ -90,24 +91,50 @@ class MSDeformAttn(nn.Module):
             assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == len_in
             self._validated = key
 
-    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None):
-        """query (N, Lq, C); reference_points (N, Lq, n_levels, n_points, 2) in [0,1] -- MVDeTr's 5-D
-        form (ms_deform_attn.py:104-107) -- or (..., 4) boxes; input_flatten (N, sum H_l*W_l, C);
-        input_spatial_shapes (n_levels, 2); input_level_start_index (n_levels,);
-        input_padding_mask (N, sum H_l*W_l) True = padding.  Returns (N, Lq, C)."""
-        N, Len_q, _ = query.shape
-        N, Len_in, _ = input_flatten.shape
-        self._check_lengths(input_spatial_shapes, Len_in)
-
+    def project_value(self, input_flatten, input_padding_mask=None):
+        """value_proj + padding mask (ms_deform_attn.py:96-98) on any subset of the tokens: (N, n, C) ->
+        (N, n, C).  Split out so that a query-sharded run can project its own tokens and all-gather the result
+        (mvdetr_amd/dist.py) instead of projecting every token on every rank."""
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
+        return value
+
+    def _check_query_levels(self, spatial_shapes, query_levels, len_q):
+        key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(query_levels), len_q)
+        if self._validated_q != key:
+            l0, l1 = query_levels
+            assert 0 <= l0 < l1 <= spatial_shapes.shape[0]
+            assert int((spatial_shapes[l0:l1, 0] * spatial_shapes[l0:l1, 1]).sum()) == len_q
+            self._validated_q = key
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None, *, query_levels=None, projected_value=None):
+        """query (N, Lq, C); reference_points (N, Lq, n_levels, n_points, 2) in [0,1] -- MVDeTr's 5-D
+        form (ms_deform_attn.py:104-107) -- or (..., 4) boxes; input_flatten (N, sum H_l*W_l, C);
+        input_spatial_shapes (n_levels, 2); input_level_start_index (n_levels,);
+        input_padding_mask (N, sum H_l*W_l) True = padding.  Returns (N, Lq, C).
+
+        Two keyword extensions for the query-sharded encoder (not in the reference): ``projected_value``
+        (N, sum H_l*W_l, C) = project_value() of all tokens, used instead of projecting ``input_flatten`` here;
+        ``query_levels=(l0, l1)`` promises that the Lq queries are exactly the tokens of levels l0..l1-1, which
+        lets the fused kernel take the call (it is only a hint: results do not depend on it)."""
+        N, Len_q, _ = query.shape
+        if projected_value is not None:
+            value = projected_value
+            Len_in = value.shape[1]
+            self._check_lengths(input_spatial_shapes, Len_in)
+        else:
+            Len_in = input_flatten.shape[1]
+            self._check_lengths(input_spatial_shapes, Len_in)
+            value = self.project_value(input_flatten, input_padding_mask)
         value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        if query_levels is not None:
+            self._check_query_levels(input_spatial_shapes, query_levels, Len_q)
         if (self.fused_inference and reference_points.shape[-1] == 2 and reference_points.dim() == 5
                 and not (torch.is_grad_enabled() and (value.requires_grad or query.requires_grad
                                                       or self.sampling_offsets.weight.requires_grad))
-                and MSDA.fused_supported(value, self.n_levels, Len_q, self.n_points)):
+                and MSDA.fused_supported(value, self.n_levels, Len_q, self.n_points, query_levels)):
             # one GEMM for offsets + logits, rows permuted to level-major (see _fused_projection)
             w, b = self._fused_projection()
             raw = F.linear(query, w, b)
@@ -116,7 +143,7 @@ class MSDeformAttn(nn.Module):
             out = MSDA.ms_deform_attn_forward_fused(
                 value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,
                 raw[..., :n_off].unflatten(-1, (L, M, P, 2)), raw[..., n_off:].unflatten(-1, (L, M, P)),
-                level_major=True)
+                level_major=True, query_levels=query_levels)
             return self.output_proj(out)
         offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)

@@ -67,9 +67,14 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def with_pos_embed(tensor, pos):
         return tensor if pos is None else tensor + pos
 
-    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, *,
+                query_levels=None, projected_value=None):
+        """deformable_transformer.py:88-100.  With ``projected_value`` (self_attn.project_value of ALL tokens)
+        ``src``/``pos``/``reference_points`` may hold only the queries of levels ``query_levels`` -- one rank's
+        share of a query-sharded layer (mvdetr_amd/dist.py); the layer is per-token apart from the attention."""
         attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
-                              level_start_index, padding_mask)
+                              level_start_index, padding_mask, query_levels=query_levels,
+                              projected_value=projected_value)
         src = self.norm1(src + self.dropout1(attn))
         ffn = self.linear2(self.dropout2(F.relu(self.linear1(src))))
         return self.norm2(src + self.dropout3(ffn))
@@ -140,13 +145,18 @@ class DeformTransWorldFeat(nn.Module):
         tok = y.permute(0, 2, 3, 1).reshape(B, N * h * w, self.hidden_dim)   # free if y is channels_last
         return tok, h, w
 
+    def level_pos(self, h, w):
+        """Position + camera embedding of every token, [1, N*h*w, C] (trans_world_feat.py:95-98)."""
+        N, C = self.num_cam, self.hidden_dim
+        pos = self.pos_embedding.flatten(2).transpose(1, 2).unsqueeze(1)                 # [1,1,hw,C]
+        return (pos + self.lvl_embedding.view(1, N, 1, C)).reshape(1, N * h * w, C)      # any B
+
     def fuse(self, src, B, h, w):
         """[B, N*h*w, C] tokens of ALL cameras -> merged BEV feature [B, C, H, W]: level/position
         embedding, 3 deformable encoder layers, per-camera 1x1 merge, upsample (trans_world_feat.py:93-110).
         Split from tokens() so a view-sharded run can all-gather between the two (mvdetr_amd/dist.py)."""
         N, C = self.num_cam, self.hidden_dim
-        pos = self.pos_embedding.flatten(2).transpose(1, 2).unsqueeze(1)                 # [1,1,hw,C]
-        lvl_pos = (pos + self.lvl_embedding.view(1, N, 1, C)).reshape(1, N * h * w, C)   # any B
+        lvl_pos = self.level_pos(h, w)
         memory = self.encoder(src, self.spatial_shapes, self.level_start_index, None, lvl_pos)
         merged = memory.view(B, N, h, w, C).permute(0, 1, 4, 2, 3).reshape(B, N * C, h, w)
         return self.upsample(self.merge_linear(merged))

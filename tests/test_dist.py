@@ -78,3 +78,95 @@ def test_view_sharded_all_gather_world2(num_views):
         p.join(timeout=60)
     for rank, ok, msg in results:
         assert ok, f"rank {rank}: {msg}"
+
+
+# ---- query-sharded encoder ---------------------------------------------------
+# The product's attention core is the HIP extension and has no CPU form; for these CPU tests of the
+# *communication schedule* the extension's forward entry is replaced by the oracle (test infrastructure).
+
+def _oracle_core_patch(monkeypatch=None):
+    """monkeypatch=None only inside a spawned worker process (nothing to restore there)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import torch_oracle
+    from mvdetr_amd.ops import MultiScaleDeformableAttention as MSDA
+
+    def forward(value, shapes, lsi, loc, aw, im2col_step):
+        return torch_oracle.msda_core(value, shapes, loc, aw)
+    if monkeypatch is None:
+        MSDA.ms_deform_attn_forward = forward
+    else:
+        monkeypatch.setattr(MSDA, "ms_deform_attn_forward", forward)
+
+
+def _small_world_feat(num_views, C=16, H=8, W=12, seed=0):
+    from mvdetr_amd.world_feat import DeformTransWorldFeat
+    torch.manual_seed(seed)
+    h, w = H // 2, W // 2
+    ref = torch.rand(num_views * h * w, num_views, 4, 2, generator=torch.Generator().manual_seed(3))
+    wf = DeformTransWorldFeat(num_views, (H, W), C, hidden_dim=C, nhead=2, dim_feedforward=32, reference_points=ref)
+    # the zero-initialised offset/attention weights would make every query of a camera behave alike
+    for layer in wf.encoder.layers:
+        torch.nn.init.normal_(layer.self_attn.sampling_offsets.weight, std=0.3)
+        torch.nn.init.normal_(layer.self_attn.attention_weights.weight, std=0.3)
+    return wf.eval(), h, w
+
+
+@pytest.mark.parametrize("num_views,world", [(7, 3), (7, 8), (6, 4), (3, 1), (16, 8)])
+def test_query_sharded_fusion_lockstep(num_views, world, monkeypatch):
+    """Emulated ranks in one process: per-layer value exchange + partial merge == unsharded fuse()."""
+    _oracle_core_patch(monkeypatch)
+    wf, h, w = _small_world_feat(num_views)
+    B, C = 2, wf.hidden_dim
+    tokens = torch.randn(B, num_views * h * w, C, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        want = wf.fuse(tokens, B, h, w)
+        ranks = [mdist.QueryShardedFusion(wf, r, world) for r in range(world)]
+        src = [tokens[:, rk.own_slice(h, w)] for rk in ranks]
+        for i in range(wf.encoder.num_layers):
+            value = torch.cat([rk.layer_value(i, s) for rk, s in zip(ranks, src)], dim=1)
+            assert value.shape == tokens.shape
+            src = [rk.layer_update(i, s, value, h, w) for rk, s in zip(ranks, src)]
+        total = sum(rk.merge_partial(s, B, h, w) for rk, s in zip(ranks, src))
+        got = ranks[0].merge_finish(total)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-5), float((got - want).abs().max())
+
+
+def _sharded_worker(rank, world, port, num_views, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    try:
+        mdist.init_from_env()
+        _oracle_core_patch()
+        wf, h, w = _small_world_feat(num_views)
+        B, C = 2, wf.hidden_dim
+        tokens = torch.randn(B, num_views * h * w, C, generator=torch.Generator().manual_seed(9))
+        with torch.no_grad():
+            want = wf.fuse(tokens, B, h, w)
+        fusion = mdist.QueryShardedFusion(wf, rank, world)
+        got = fusion(tokens[:, fusion.own_slice(h, w)].contiguous(), B, h, w)
+        ok = got.shape == want.shape and torch.allclose(got, want, atol=2e-5, rtol=1e-5)
+        q.put((rank, bool(ok), "" if ok else f"max err {float((got - want).abs().max())}"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_views", [7, 1])
+def test_query_sharded_fusion_world2(num_views):
+    """The same through real collectives (gloo, world size 2; with one view rank 1 is idle)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, num_views, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in results:
+        assert ok, f"rank {rank}: {msg}"

@@ -540,3 +540,67 @@ def test_fused_seven_unequal_levels_take_the_tile_kernel(ops):
     aw = torch.softmax(logit_hm.flatten(3), -1).view(1, S, 8, 7, 4)
     want = torch_oracle.msda_core(value, shapes, loc, aw)
     assert (out - want).abs().max().item() < FP32_TOL
+
+
+# ---- query levels: one rank's share of a query-sharded encoder layer ---------------
+QL_CASES = {
+    "wildtrack-like": ([(13, 21)] * 7, 8, 16, 1, [(0, 1), (3, 4), (6, 7), (2, 5), (0, 7)]),
+    "two-per-rank": ([(9, 17)] * 6, 8, 16, 2, [(0, 2), (2, 4), (4, 6)]),
+    "unequal": ([(12, 20), (6, 10), (12, 20), (3, 5), (8, 8)], 8, 16, 1, [(0, 1), (1, 3), (3, 5), (4, 5)]),
+    "d32": ([(10, 18)] * 4, 8, 32, 1, [(1, 2), (2, 4)]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(QL_CASES))
+@pytest.mark.parametrize("level_major", [False, True])
+def test_fused_query_levels_vs_full_call_and_oracle(ops, case, level_major):
+    """Restricting the queries to the tokens of levels [l0, l1) returns exactly those rows of the full call."""
+    from helpers import pyramid_encoder_inputs
+    _, MSDA = ops
+    lv, M, D, B, ranges = QL_CASES[case]
+    L, P = len(lv), 4
+    value, shapes, lsi, _, _ = pyramid_encoder_inputs(lv, M=M, D=D, B=B, seed=11)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(7)
+    off = torch.randn(B, S, M, L, P, 2, generator=g) * 1.5
+    logit = torch.randn(B, S, M, L, P, generator=g)
+    refs = []
+    for H, W in lv:
+        ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+        refs.append(torch.stack([xs / W, ys / H], -1).reshape(-1, 2))
+    ref = torch.cat(refs, 0).view(1, S, 1, 1, 2).repeat(B, 1, L, P, 1) + 0.002 * torch.randn(B, S, L, P, 2, generator=g)
+    loc = torch_oracle.msda_sampling_locations(ref, off, shapes)
+    aw = torch.softmax(logit.flatten(3), -1).view(B, S, M, L, P)
+    want = torch_oracle.msda_core(value, shapes, loc, aw)
+    if level_major:
+        off_k, logit_k = off.permute(0, 1, 3, 2, 4, 5).contiguous(), logit.permute(0, 1, 3, 2, 4).contiguous()
+    else:
+        off_k, logit_k = off, logit
+    value_d, shapes_d, lsi_d = dev(value, shapes, lsi)
+    full = MSDA.ms_deform_attn_forward_fused(value_d, shapes_d, lsi_d, *dev(ref, off_k, logit_k), level_major=level_major)
+    assert (full.cpu() - want).abs().max().item() < FP32_TOL
+    starts = lsi.tolist() + [S]
+    for l0, l1 in ranges:
+        q0, q1 = starts[l0], starts[l1]
+        assert MSDA.fused_supported(value_d, L, q1 - q0, P, (l0, l1))
+        part = MSDA.ms_deform_attn_forward_fused(
+            value_d, shapes_d, lsi_d, *dev(ref[:, q0:q1].contiguous(), off_k[:, q0:q1].contiguous(),
+                                           logit_k[:, q0:q1].contiguous()),
+            level_major=level_major, query_levels=(l0, l1))
+        assert MSDA.last_forward_impl() == "tile_fused"
+        assert part.shape == (B, q1 - q0, M * D)
+        assert (part.cpu() - want[:, q0:q1]).abs().max().item() < FP32_TOL, (l0, l1)
+        if (l0, l1) != (0, L) or not (L in (6, 7) and len(set(lv)) == 1):
+            # same kernel, same summation order as the rows of the full call (the grouped kernel, which serves
+            # the full call for 6 or 7 equal cameras, sums in another order)
+            assert (part - full[:, q0:q1]).abs().max().item() < 2e-5
+
+
+def test_fused_query_levels_rejects_inconsistent_ranges(ops):
+    _, MSDA = ops
+    value = torch.randn(1, 4 * 6 * 8, 8, 16, device="cuda")
+    assert MSDA.fused_supported(value, 4, 48, 4, (1, 2))
+    assert not MSDA.fused_supported(value, 4, 48, 4, (2, 2))
+    assert not MSDA.fused_supported(value, 4, 48, 4, (3, 5))
+    assert not MSDA.fused_supported(value, 4, 4 * 48 + 1, 4, (0, 3))
+    assert not MSDA.fused_supported(value, 4, 48, 4, None)            # all levels need Lq == S

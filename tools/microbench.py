@@ -77,6 +77,24 @@ def main():
             fn = lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, go, 64)  # noqa: E731
             report(f"msda_bwd[{tag}] (+memset)", time_us(fn, max(5, a.iters // 5)), bwd_bytes)
 
+    # fused entry (what the model calls in inference), all query levels and one rank's share (query-sharded)
+    g = torch.Generator().manual_seed(0)
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(1, H * W, 1, 1, 2).repeat(1, L, L, P, 1).cuda()
+    raw = torch.randn(B, S, L * M * P * 3, generator=g).cuda()          # [offsets | logits], level-major
+    n_off = L * M * P * 2
+    off, logit = raw[..., :n_off].unflatten(-1, (L, M, P, 2)), raw[..., n_off:].unflatten(-1, (L, M, P))
+    value, shapes, lsi = [x.cuda() for x in encoder_msda_inputs(L, H, W, M, D, P, B=B, seed=0)[:3]]
+    fn = lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, ref, off, logit, level_major=True)  # noqa: E731
+    report("msda_fwd_fused[all levels]", time_us(fn, a.iters), fwd_bytes)
+    for n_own in (1, 2):
+        q = n_own * H * W
+        own_bytes = 4 * B * (S * M * D + 3 * q * M * L * P + q * M * D)
+        o2, l2, r2 = off[:, :q], logit[:, :q], ref[:, :q]
+        fn = lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, r2, o2, l2, level_major=True,  # noqa: E731
+                                                       query_levels=(0, n_own))
+        report(f"msda_fwd_fused[{n_own} of {L} levels]", time_us(fn, a.iters), own_bytes)
+
     h, w = geom.Rimg_shape
     Hw, Ww = geom.Rworld_shape
     Ks, Rts = geometry.synthetic_rig(geom, seed=0)
