@@ -120,8 +120,11 @@ int mvdetr_msda_backward_f64(void *stream, const double *grad_col, const double 
  *   src  [n, channels, src_h, src_w]        (NCHW, like the reference's imgs_feat)
  *   M    [n, 3, 3]  destination pixel <- source pixel homography, same dtype as src
  *   dst  [n, channels, dst_h, dst_w]        every element is written (zeros outside the view)
- * `layout_nhwc` != 0 writes dst as [n, dst_h, dst_w, channels] instead (the token layout the
- * shadow transformer consumes, trans_world_feat.py:92), saving the permute copy.
+ * `layout_nhwc` is a bit mask.  Bit 0 (value 1): dst is written as [n, dst_h, dst_w, channels] instead (the
+ * token layout the shadow transformer consumes, trans_world_feat.py:92), saving the permute copy.  Bit 1
+ * (value 2): src is [n, src_h, src_w, channels] -- what a channels_last trunk produces -- so every bilinear
+ * corner is one contiguous channel vector; supported together with bit 0 (value 3), channels a multiple of
+ * 16 bytes, 16-byte aligned pointers; hipErrorNotSupported (801) otherwise.  Other bits: hipErrorInvalidValue.
  */
 int mvdetr_warp_perspective_forward_f32(void *stream, const float *src, const float *M, int n,
                                         int channels, int src_h, int src_w, int dst_h, int dst_w,
@@ -131,8 +134,9 @@ int mvdetr_warp_perspective_forward_f64(void *stream, const double *src, const d
                                         int layout_nhwc, double *dst);
 
 /* Gradient of the warp w.r.t. src (what autograd reaches through grid_sample in the reference).
- *   grad_dst [n, channels, dst_h, dst_w] (or NHWC if layout_nhwc)
- *   grad_src [n, channels, src_h, src_w]; MUST BE ZERO on entry (accumulated with atomics)
+ *   grad_dst [n, channels, dst_h, dst_w] (or NHWC if layout_nhwc bit 0)
+ *   grad_src [n, channels, src_h, src_w] (or NHWC if layout_nhwc bit 1, same restrictions as the forward);
+ *            MUST BE ZERO on entry (accumulated with atomics)
  */
 int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, const float *M, int n,
                                          int channels, int src_h, int src_w, int dst_h, int dst_w,

@@ -219,6 +219,118 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_bwd(
     }
 }
 
+// ---- channel-last source AND destination ---------------------------------------------------------------
+// The layout a channels_last trunk hands over ([N,h,w,C] memory under an NCHW-shaped tensor) and the one the
+// shadow transformer's tokens want.  The NCHW-source kernel above gathers 4-byte texels, one load
+// instruction per (channel, corner row): at Wildtrack size ~10 M wave-level gathers, i.e. it runs at the
+// texture-address rate (93 us vs 33 us for a copy of the same bytes).  With channels innermost a corner is a
+// contiguous C-vector: a lane takes 16 bytes of it, the C/4 (fp32) lanes of a pixel read whole 512-byte rows,
+// and a pixel's geometry is evaluated once (fp64) by one lane and shared through LDS instead of once per
+// channel group.
+template <typename T> struct WarpTexel {
+    int o00;                     // element offset of corner (y0, x0) inside the view, in texels (not scaled by C)
+    T w00, w01, w10, w11;
+    int valid;                   // bit 0..3: corners 00, 01, 10, 11 inside the source
+};
+
+template <typename T>
+__device__ __forceinline__ WarpTexel<T> warp_texel(const T *__restrict__ Mn, int i, int j, int h, int w, bool live)
+{
+    WarpTexel<T> t;
+    t.o00 = 0;
+    t.valid = 0;
+    t.w00 = t.w01 = t.w10 = t.w11 = T(0);
+    if (live) {
+        double x, y;
+        source_position(Mn, i, j, h, w, x, y);
+        const SrcCoord sc = make_coord(x, y, h, w);
+        t.o00 = sc.y0 * w + sc.x0;
+        t.w00 = T(sc.wy0 * sc.wx0);
+        t.w01 = T(sc.wy0 * sc.wx1);
+        t.w10 = T(sc.wy1 * sc.wx0);
+        t.w11 = T(sc.wy1 * sc.wx1);
+        t.valid = (sc.v00 ? 1 : 0) | (sc.v01 ? 2 : 0) | (sc.v10 ? 4 : 0) | (sc.v11 ? 8 : 0);
+    }
+    return t;
+}
+
+constexpr int WARP_CL_THREADS = 256;
+
+template <typename T>
+__global__ __launch_bounds__(WARP_CL_THREADS) void warp_fwd_cl(
+    const T *__restrict__ src, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
+    T *__restrict__ dst)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ WarpTexel<T> tex[WARP_PIX];
+    WarpBlock wb;
+    if (!warp_block(N, H, W, 1, wb)) return;
+    const int n = wb.n;
+    if (threadIdx.x < WARP_PIX) {
+        const int i = wb.i0 + threadIdx.x / WARP_TW, j = wb.j0 + threadIdx.x % WARP_TW;
+        tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W);
+    }
+    __syncthreads();
+    const int chunks = C / VEC;                                   // 16-byte chunks per pixel
+    const T *view = src + (int64_t)n * h * w * C;
+    const int rowC = w * C;
+    for (int item = threadIdx.x; item < WARP_PIX * chunks; item += WARP_CL_THREADS) {
+        const int p = item / chunks, c = (item - p * chunks) * VEC;
+        const int i = wb.i0 + p / WARP_TW, j = wb.j0 + p % WARP_TW;
+        if (i >= H || j >= W) continue;
+        const WarpTexel<T> t = tex[p];
+        Pack<T, VEC> out = Pack<T, VEC>::zero();
+        if (t.valid) {
+            const T *sp = view + (int64_t)t.o00 * C + c;
+            const Pack<T, VEC> z = Pack<T, VEC>::zero();
+            const Pack<T, VEC> a = (t.valid & 1) ? Pack<T, VEC>::load(sp) : z;
+            const Pack<T, VEC> b = (t.valid & 2) ? Pack<T, VEC>::load(sp + C) : z;
+            const Pack<T, VEC> cc = (t.valid & 4) ? Pack<T, VEC>::load(sp + rowC) : z;
+            const Pack<T, VEC> d = (t.valid & 8) ? Pack<T, VEC>::load(sp + rowC + C) : z;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) out.v[k] = t.w00 * a.v[k] + t.w01 * b.v[k] + t.w10 * cc.v[k] + t.w11 * d.v[k];
+        }
+        out.store(dst + (((int64_t)n * H + i) * W + j) * C + c);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
+    const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
+    T *__restrict__ grad_src)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ WarpTexel<T> tex[WARP_PIX];
+    WarpBlock wb;
+    if (!warp_block(N, H, W, 1, wb)) return;
+    const int n = wb.n;
+    if (threadIdx.x < WARP_PIX) {
+        const int i = wb.i0 + threadIdx.x / WARP_TW, j = wb.j0 + threadIdx.x % WARP_TW;
+        tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W);
+    }
+    __syncthreads();
+    const int chunks = C / VEC;
+    T *view = grad_src + (int64_t)n * h * w * C;
+    const int rowC = w * C;
+    for (int item = threadIdx.x; item < WARP_PIX * chunks; item += WARP_CL_THREADS) {
+        const int p = item / chunks, c = (item - p * chunks) * VEC;
+        const int i = wb.i0 + p / WARP_TW, j = wb.j0 + p % WARP_TW;
+        if (i >= H || j >= W) continue;
+        const WarpTexel<T> t = tex[p];
+        if (!t.valid) continue;
+        const Pack<T, VEC> g = Pack<T, VEC>::load(grad_dst + (((int64_t)n * H + i) * W + j) * C + c);
+        T *gp = view + (int64_t)t.o00 * C + c;
+        // the lanes of a pixel cover its whole C-row: each atomic instruction is a run of contiguous segments
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            if (t.valid & 1) atomicAdd(gp + k, t.w00 * g.v[k]);
+            if (t.valid & 2) atomicAdd(gp + C + k, t.w01 * g.v[k]);
+            if (t.valid & 4) atomicAdd(gp + rowC + k, t.w10 * g.v[k]);
+            if (t.valid & 8) atomicAdd(gp + rowC + C + k, t.w11 * g.v[k]);
+        }
+    }
+}
+
 template <typename T>
 static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int N, int C, int h, int w,
                       int H, int W, int nhwc, T *o)
@@ -227,10 +339,25 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
     const int64_t npix = (int64_t)N * H * W;
     if (npix == 0 || C == 0) return 0;
     if (!a || !Mv || !o) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (nhwc & ~3) return (int)hipErrorInvalidValue;
+    if (nhwc & 2) {
+        // channel-last source: implemented for channel-last destinations, whole 16-byte chunks per pixel and a
+        // view that fits 32-bit element offsets
+        constexpr int VEC = 16 / (int)sizeof(T);
+        if (!(nhwc & 1) || C % VEC || !aligned(a, 16) || !aligned(o, 16) || (int64_t)h * w * C > 0x7fffffffLL)
+            return (int)hipErrorNotSupported;
+        const int64_t nb = warp_grid(N, H, W, 1);
+        if (nb > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        if (!backward)
+            hipLaunchKernelGGL((warp_fwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, o);
+        else
+            hipLaunchKernelGGL((warp_bwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, o);
+        return (int)hipGetLastError();
+    }
     const int groups = (C + WARP_CH - 1) / WARP_CH;
     const int64_t blocks = warp_grid(N, H, W, groups);
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)blocks), block(WARP_PIX * WARP_SUB);
     if (!backward) {
         if (nhwc) hipLaunchKernelGGL((warp_fwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);

@@ -13,12 +13,23 @@ from torch.autograd.function import once_differentiable
 from .. import _lib
 
 
-def _launch(name, a, M, n, c, h, w, H, W, nhwc, out):
+DST_NHWC, SRC_NHWC = 1, 2          # bits of the C ABI's layout_nhwc argument (include/mvdetr_ops.h)
+
+
+def _launch(name, a, M, n, c, h, w, H, W, layout, out):
     with torch.cuda.device(a.device):
         rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_{name}_{_lib.suffix(a.dtype)}")(
-            _lib.current_stream_ptr(a.device), a.data_ptr(), M.data_ptr(), n, c, h, w, H, W,
-            1 if nhwc else 0, out.data_ptr())
+            _lib.current_stream_ptr(a.device), a.data_ptr(), M.data_ptr(), n, c, h, w, H, W, layout,
+            out.data_ptr())
     _lib.check(rc, f"warp_perspective_{name}")
+
+
+def _channel_last_source(src, channels_last_out):
+    """True when ``src`` ([N,C,h,w] shape) already lies in memory as [N,h,w,C] and the channel-last kernel
+    takes it: then the warp reads it in place instead of copying it to NCHW first."""
+    n, c, h, w = src.shape
+    return (channels_last_out and c > 1 and h * w > 1 and src.is_contiguous(memory_format=torch.channels_last)
+            and not src.is_contiguous() and (c * src.element_size()) % 16 == 0 and src.data_ptr() % 16 == 0)
 
 
 class WarpPerspectiveFunction(Function):
@@ -26,20 +37,26 @@ class WarpPerspectiveFunction(Function):
     def forward(ctx, src, M, dsize, channels_last_out):
         n, c, h, w = src.shape
         H, W = int(dsize[0]), int(dsize[1])
+        src_cl = _channel_last_source(src, channels_last_out)
+        if not src_cl:
+            src = src.contiguous()
+        layout = (DST_NHWC if channels_last_out else 0) | (SRC_NHWC if src_cl else 0)
         shape = (n, H, W, c) if channels_last_out else (n, c, H, W)
         out = torch.empty(shape, dtype=src.dtype, device=src.device)
-        _launch("forward", src, M, n, c, h, w, H, W, channels_last_out, out)
+        _launch("forward", src, M, n, c, h, w, H, W, layout, out)
         ctx.save_for_backward(M)
-        ctx.geom = (n, c, h, w, H, W, channels_last_out)
+        ctx.geom = (n, c, h, w, H, W, layout)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
         (M,) = ctx.saved_tensors
-        n, c, h, w, H, W, nhwc = ctx.geom
-        grad_src = torch.zeros((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device)
-        _launch("backward", grad_out.contiguous(), M, n, c, h, w, H, W, nhwc, grad_src)
+        n, c, h, w, H, W, layout = ctx.geom
+        grad_src = torch.empty((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device,
+                               memory_format=torch.channels_last if layout & SRC_NHWC
+                               else torch.contiguous_format).zero_()
+        _launch("backward", grad_out.contiguous(), M, n, c, h, w, H, W, layout, grad_src)
         return grad_src, None, None, None
 
 
@@ -48,6 +65,9 @@ def warp_perspective(src, M, dsize, mode="bilinear", padding_mode="zeros", align
     """src [N,C,h,w] -> [N,C,H,W] (or [N,H,W,C] with ``channels_last_out``), sampling the source at
     the pre-image of every destination pixel under ``M [N,3,3]`` (destination pixel <- source
     pixel), with kornia's normalisation convention.
+
+    A ``src`` in ``torch.channels_last`` memory format is read in place when ``channels_last_out`` is set
+    (no NCHW copy; every bilinear corner is then one contiguous channel vector).
 
     ``M`` may live on the CPU (mvdetr.py:194 moves it each call); it is copied to ``src``'s device.
     Only the configuration MVDeTr's model uses is implemented natively: bilinear, zero padding,
@@ -63,4 +83,4 @@ def warp_perspective(src, M, dsize, mode="bilinear", padding_mode="zeros", align
     if not src.is_cuda:
         raise RuntimeError("warp_perspective: not implemented on the CPU (HIP extension only)")
     M = M.reshape(-1, 3, 3).to(device=src.device, dtype=src.dtype).contiguous()
-    return WarpPerspectiveFunction.apply(src.contiguous(), M, tuple(dsize), bool(channels_last_out))
+    return WarpPerspectiveFunction.apply(src, M, tuple(dsize), bool(channels_last_out))

@@ -135,3 +135,74 @@ def test_identity_homography_shows_kornia_normalisation_quirk(warp):
     expect[0] = 0.5 * 0.0 + 0.5 * 0.0      # x = -0.5: half of pixel 0 (value 0) and half padding
     expect[7] = 0.5 * 7.0                  # x = 7.5: half of pixel 7, half padding
     assert (out - expect).abs().max().item() < 1e-5
+
+
+# ---- channel-last SOURCE (what a channels_last trunk hands over), read in place ------------------------
+def _count_kernel_calls(monkeypatch):
+    """Records the layout flag of every launch (1 = NHWC destination, 2 = NHWC source)."""
+    from mvdetr_amd.ops import warp as warp_mod
+    seen = []
+    real = warp_mod._launch
+
+    def spy(name, a, M, n, c, h, w, H, W, layout, out):
+        seen.append((name, layout))
+        return real(name, a, M, n, c, h, w, H, W, layout, out)
+    monkeypatch.setattr(warp_mod, "_launch", spy)
+    return seen
+
+
+@pytest.mark.parametrize("aug", [None, 5])
+def test_channels_last_source_wildtrack(warp, aug, monkeypatch):
+    seen = _count_kernel_calls(monkeypatch)
+    M = wildtrack_mats(aug)
+    src = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(6))
+    src_cl = src.cuda().contiguous(memory_format=torch.channels_last)
+    out = warp(src_cl, M, (120, 360), channels_last_out=True)
+    assert seen[-1] == ("forward", 3)                               # the in-place kernel ran, not a copy + NCHW kernel
+    assert out.shape == (7, 120, 360, 128) and out.is_contiguous()
+    _against_both_oracles(out.permute(0, 3, 1, 2).cpu(), src, M, frac_within=0.99)
+    plain = warp(src.cuda(), M, (120, 360), channels_last_out=True)
+    assert seen[-1] == ("forward", 1)
+    assert (out - plain).abs().max().item() < 2e-6                  # same weights, possibly another fma contraction
+    assert torch.equal(out == 0, plain == 0)
+    # an NCHW destination of a channel-last source goes through the copy (documented restriction)
+    nchw = warp(src_cl, M, (120, 360))
+    assert seen[-1] == ("forward", 0) and torch.equal(nchw, warp(src.cuda(), M, (120, 360)))
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 8), (torch.float32, 36), (torch.float64, 6), (torch.float32, 6)])
+def test_channels_last_source_small_and_ragged(warp, dtype, C, monkeypatch):
+    seen = _count_kernel_calls(monkeypatch)
+    g = torch.Generator().manual_seed(C)
+    src = torch.randn(3, C, 11, 13, generator=g, dtype=dtype)
+    Ms = wildtrack_mats(None)[:3] @ torch.diag(torch.tensor([12.0, 12.0, 1.0]))
+    Ms = (torch.diag(torch.tensor([0.1, 0.1, 1.0])) @ Ms).to(dtype)
+    src_cl = src.cuda().contiguous(memory_format=torch.channels_last)
+    out = warp(src_cl, Ms, (9, 21), channels_last_out=True)
+    in_place = (C * src.element_size()) % 16 == 0
+    assert seen[-1] == ("forward", 3 if in_place else 1)            # C*size not a multiple of 16 bytes: copy path
+    ref = c_oracle.warp_perspective(src.double(), Ms.double(), (9, 21))
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert (out.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_channels_last_source_backward(warp, dtype, monkeypatch):
+    seen = _count_kernel_calls(monkeypatch)
+    g = load_golden("warp_restatement.npz")
+    src, M = t(g["src"]).to(dtype), t(g["M"])
+    src_cl = src.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = warp(src_cl, M, (12, 36), channels_last_out=True)
+    go = torch.randn(2, 8, 12, 36, generator=torch.Generator().manual_seed(4), dtype=torch.float64)
+    (gs,) = torch.autograd.grad(out, src_cl, go.permute(0, 2, 3, 1).contiguous().to(dtype).cuda())
+    assert ("forward", 3) in seen and seen[-1] == ("backward", 3)
+    assert gs.shape == src.shape and gs.is_contiguous(memory_format=torch.channels_last)
+    ref = c_oracle.warp_perspective_backward(go, M, (9, 16))
+    assert (gs.cpu().double() - ref).abs().max().item() < (1e-10 if dtype == torch.float64 else 1e-4)
+
+
+def test_channels_last_source_gradcheck(warp):
+    g = load_golden("warp_restatement.npz")
+    src = t(g["src"])[:, :4].contiguous().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    M = t(g["M"])
+    assert torch.autograd.gradcheck(lambda s: warp(s, M, (6, 10), channels_last_out=True), (src,))

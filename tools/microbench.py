@@ -104,6 +104,8 @@ def main():
     wbytes = 4 * L * C * (h * w + Hw * Ww)
     report("warp_fwd NCHW", time_us(lambda: warp_perspective(src, Mx, (Hw, Ww)), a.iters), wbytes)
     report("warp_fwd NHWC", time_us(lambda: warp_perspective(src, Mx, (Hw, Ww), channels_last_out=True), a.iters), wbytes)
+    src_cl = src.contiguous(memory_format=torch.channels_last)
+    report("warp_fwd NHWC <- NHWC source", time_us(lambda: warp_perspective(src_cl, Mx, (Hw, Ww), channels_last_out=True), a.iters), wbytes)
     # for scale: a plain device copy of the same number of bytes
     x = torch.empty(wbytes // 8, device="cuda")
     y = torch.empty_like(x)
