@@ -15,6 +15,7 @@
 // -munsafe-fp-atomics), i.e. the summation order -- like the reference's atomicAdd
 // (cuh:125-152) -- is not deterministic.
 #include "common.h"
+#include "msda_dispatch.h"
 #include "../../include/mvdetr_ops.h"
 #include <stdlib.h>
 #include <string.h>
@@ -30,7 +31,8 @@ template <typename T, int G> __device__ __forceinline__ T group_sum(T v)
     return v;
 }
 
-template <typename T, int VEC, int G>
+// VALUE_GRAD = false: grad_sampling_loc / grad_attn_weight only (grad_value comes from msda_backward_tile.hip)
+template <typename T, int VEC, int G, bool VALUE_GRAD = true>
 __global__ __launch_bounds__(256) void msda_bwd_lanes(
     const T *__restrict__ grad_col, const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const T *__restrict__ loc, const T *__restrict__ aw, int B, int S,
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void msda_bwd_lanes(
                     g_a += g * (w00 * c00.v[i] + w01 * c01.v[i] + w10 * c10.v[i] + w11 * c11.v[i]);
                     g_x += g * ((c01.v[i] - c00.v[i]) * f.wy0 + (c11.v[i] - c10.v[i]) * f.wy1);
                     g_y += g * ((c10.v[i] - c00.v[i]) * f.wx0 + (c11.v[i] - c01.v[i]) * f.wx1);
-                    if (live) {
+                    if (VALUE_GRAD && live) {
                         const T ga = g * a;
                         if (v00) atomic_add(grad_value + o00 + i, w00 * ga);
                         if (v01) atomic_add(grad_value + o01 + i, w01 * ga);
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void msda_bwd_serial(
 
 #define MSDA_BWD_ARGS grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, grad_value, grad_loc, grad_aw
 
-template <typename T, int VEC, int G>
+template <typename T, int VEC, int G, bool VALUE_GRAD = true>
 static int launch_lanes(hipStream_t st, const T *grad_col, const T *value, const int64_t *shapes,
                         const int64_t *lsi, const T *loc, const T *aw, int B, int S, int M, int D, int L,
                         int Lq, int P, T *grad_value, T *grad_loc, T *grad_aw)
@@ -164,7 +166,7 @@ static int launch_lanes(hipStream_t st, const T *grad_col, const T *value, const
     const int64_t total = (int64_t)B * Lq * M * G;
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((msda_bwd_lanes<T, VEC, G>), dim3((unsigned)blocks), dim3(256), 0, st, MSDA_BWD_ARGS);
+    hipLaunchKernelGGL((msda_bwd_lanes<T, VEC, G, VALUE_GRAD>), dim3((unsigned)blocks), dim3(256), 0, st, MSDA_BWD_ARGS);
     return (int)hipGetLastError();
 }
 
@@ -180,6 +182,18 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     constexpr int WIDE = 16 / (int)sizeof(T);
     const bool a16 = aligned(value, 16) && aligned(grad_col, 16);
+    if constexpr (sizeof(T) == 4) {
+        // Encoder-shaped fp32 calls (the shapes the forward tile kernels take): grad_value through fixed-point LDS
+        // windows (msda_backward_tile.hip), the other two gradients from the lane kernel without its atomics.
+        // MVDETR_MSDA_BWD_IMPL=atomic keeps everything on the direct-atomics kernel.
+        static const bool tile_ok = [] { const char *e = getenv("MVDETR_MSDA_BWD_IMPL"); return !(e && !strcmp(e, "atomic")); }();
+        const bool all16 = a16 && aligned(loc, 16) && aligned(aw, 16) && aligned(grad_value, 16);
+        if (tile_ok && msda_tile_supported(B, S, M, D, L, Lq, P, all16, 0, L)) {
+            int rc = msda_backward_value_tile(st, grad_col, shapes, lsi, loc, aw, B, S, M, D, L, grad_value);
+            if (rc) return rc;
+            return D == 16 ? launch_lanes<T, 1, 16, false>(st, MSDA_BWD_ARGS) : launch_lanes<T, 1, 32, false>(st, MSDA_BWD_ARGS);
+        }
+    }
     // One channel per lane (G = D lanes per head): a wave's atomic instruction then covers whole
     // 4*D-byte head segments, which the memory-side atomic units take as ONE request each, instead of four
     // partial ones with 16-byte-per-lane vectors (measured at Wildtrack size: 3.15 ms vs 12.7 ms -- the

@@ -32,6 +32,10 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
                             int level_major, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
                             int M, int D, int L, float *out);
 
+// grad_value of encoder-shaped fp32 calls through fixed-point LDS windows (msda_backward_tile.hip)
+int msda_backward_value_tile(hipStream_t st, const float *go, const int64_t *shapes, const int64_t *lsi, const float *loc,
+                             const float *aw, int B, int S, int M, int D, int L, float *grad_value);
+
 template <typename T>
 inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *aw, const T *out, int B,
                                         int S, int M, int D, int L, int Lq, int P)

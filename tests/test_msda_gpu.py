@@ -276,6 +276,8 @@ def test_wildtrack_backward_checksums(ops, wildtrack_inputs):
     out = F.apply(value, shapes, lsi, loc, aw, 64)
     lhs = (go.double() * out.double()).sum().item()
     rhs = (gv.double() * value.double()).sum().item()
+    # (grad_value comes from per-tile fixed-point windows whose step is ~1e-9 of the largest |grad_out|,
+    # msda_backward_tile.hip: as tight as with fp32 atomics)
     assert abs(lhs - rhs) < 1e-6 * (abs(lhs) + 1e3)
     # <grad_aw, aw> == <grad_out, out> as well (out is linear in aw)
     rhs2 = (ga.double() * aw.double()).sum().item()
@@ -604,3 +606,55 @@ def test_fused_query_levels_rejects_inconsistent_ranges(ops):
     assert not MSDA.fused_supported(value, 4, 48, 4, (3, 5))
     assert not MSDA.fused_supported(value, 4, 4 * 48 + 1, 4, (0, 3))
     assert not MSDA.fused_supported(value, 4, 48, 4, None)            # all levels need Lq == S
+
+
+# ---- grad_value through fixed-point LDS windows (msda_backward_tile.hip) ------------------------------------
+@pytest.mark.parametrize("variant", ["plain", "tiny", "huge", "wild_weights", "d32", "mixed_magnitudes"])
+def test_backward_fixed_point_windows_keep_fp32_accuracy(ops, variant):
+    """The encoder-shaped backward accumulates grad_value in per-tile fixed-point windows whose scale follows
+    the data: the error stays far below the 1e-4 bar relative to the gradient's own scale for tiny, huge,
+    unnormalised / negative weights and strongly mixed magnitudes alike."""
+    _, MSDA = ops
+    M, D = (4, 32) if variant == "d32" else (8, 16)
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(7, 19, 37, M=M, D=D, seed=21, noise_px=1.5)
+    go = torch.randn(1, loc.shape[1], M * D, generator=torch.Generator().manual_seed(5))
+    if variant == "tiny":
+        go = go * 1e-30
+    elif variant == "huge":
+        go = go * 1e25
+    elif variant == "wild_weights":
+        aw = (aw - 0.02) * 300.0                                   # negative and far from a softmax
+    elif variant == "mixed_magnitudes":
+        go = go * torch.logspace(-6, 3, go.shape[1]).view(1, -1, 1)        # 9 decades across the queries
+    ref = c_oracle.msda_backward(value.double(), shapes, lsi, loc.double(), aw.double(), go.double())[0]
+    gv = MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), 64)[0].cpu().double()
+    assert torch.isfinite(gv).all()
+    # per job the quantisation step is <= 2^-20 of (largest |go| * sum|aw|) among the ~100 cells of its tile
+    tile_scale = ref.abs().max().item() if variant != "mixed_magnitudes" else None
+    if tile_scale is not None:
+        assert (gv - ref).abs().max().item() < 2e-5 * tile_scale
+    else:
+        # magnitudes vary smoothly along the token axis: compare against a running local scale
+        flat_ref, flat_gv = ref.flatten(2)[0], gv.flatten(2)[0]             # [S, M*D]
+        local = torch.nn.functional.max_pool1d(flat_ref.abs().amax(1)[None, None], 1201, 1, 600)[0, 0]
+        assert ((flat_gv - flat_ref).abs().amax(1) / (local + 1e-30)).max().item() < 1e-3
+
+
+def test_backward_nonfinite_upstream_gradients_propagate_like_fp32_atomics(ops):
+    _, MSDA = ops
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(7, 12, 20, M=8, D=16, seed=22)
+    go = torch.randn(1, loc.shape[1], 128, generator=torch.Generator().manual_seed(6))
+    go[0, 33, 5] = float("inf")
+    go[0, 700, 17] = float("nan")
+    gv = MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), 64)[0].cpu()
+    ok = go.clone()
+    ok[0, 33, 5] = 0
+    ok[0, 700, 17] = 0
+    ref = c_oracle.msda_backward(value.double(), shapes, lsi, loc.double(), aw.double(), ok.double())[0]
+    gv4, ref4 = gv.view(1, -1, 8, 16), ref.view(1, -1, 8, 16)
+    bad = ~torch.isfinite(gv4)
+    assert bad[..., 0, 5].any() and bad[..., 1, 1].any()               # the poisoned channels show up ...
+    clean = torch.ones(8, 16, dtype=torch.bool)
+    clean[0, 5] = clean[1, 1] = False
+    assert torch.isfinite(gv4[..., clean]).all()                       # ... and only they
+    assert (gv4[..., clean].double() - ref4[..., clean]).abs().max().item() < 2e-4
