@@ -1,0 +1,228 @@
+// Multi-scale deformable attention backward, grad_sampling_loc and grad_attn_weight for deformable-ENCODER
+// calls -- gfx950 (MI355X).
+//
+// Both gradients are dot products of grad_out with the four bilinear corners of each tap, i.e. the forward's
+// reads with another reduction.  The generic backward (msda_backward.hip) gathers those corners from global
+// memory like the forward gather kernel (1.1 ms at Wildtrack size with its atomics switched off); here the
+// forward tile kernel's LDS staging is reused (msda_tile_body.h): a workgroup owns a (tile of query cells of one
+// level, 128-byte channel slice), stages the window of each source level in turn and takes its taps from LDS.
+// Lane = (cell, 16 channels), grad_out's 16 channels in registers; a 32-channel head is finished by adding the
+// two half lanes (neighbours in the wave).  A lane keeps its (query, head)'s results of ALL levels in registers
+// and stores them as one contiguous run: a camera-grouped variant (one staged window for all cameras' queries,
+// results stored level by level) measured 590 us against 190 us for the forward of the same structure --
+// 16/32-byte pieces 112/224 bytes apart are partial-line writes, which ECC memory turns into read-modify-writes.  Taps outside the
+// window read global memory.  Levels of unequal shape are detected on the device: msda_bwd_value_tile
+// (msda_backward_tile.hip, always launched first) then computes all three gradients and this kernel returns.
+//
+// Replaces (with msda_backward.hip / msda_backward_tile.hip) the grad_sampling_loc / grad_attn_weight half of
+// ms_deformable_col2im_cuda (multiview_detector/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-234,301-920).
+#include "common.h"
+#include "msda_dispatch.h"
+#include "msda_tile.h"
+
+namespace mvdetr {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// acc += a * b on the (x, y) and (z, w) halves: two v_pk_fma_f32, the halves are added once per tap (hsum)
+__device__ __forceinline__ f2 dot4(const float4 &a, const float4 &b, f2 acc)
+{
+    acc = __builtin_elementwise_fma((f2){a.x, a.y}, (f2){b.x, b.y}, acc);
+    return __builtin_elementwise_fma((f2){a.z, a.w}, (f2){b.z, b.w}, acc);
+}
+__device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }
+
+// d = <g, corner> for the four corners of the tap at pixel position (x, y) of a level, corners read from
+// global memory with zero padding; NV float4 chunks per lane, chunk k of `g` holds channels 4*(k^rot)..+3
+template <int NV>
+__device__ __forceinline__ void corners_from_memory(const float *__restrict__ vlevel, int64_t row, int H, int W, float x,
+                                                    float y, int rot, const float4 *g, f2 &d00, f2 &d01, f2 &d10,
+                                                    f2 &d11)
+{
+    const Footprint<float> f = footprint(y, x, H, W);
+    const float *r0 = vlevel + ((int64_t)f.y0 * W + f.x0) * row, *r1 = r0 + (int64_t)W * row;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int ko = (k ^ rot) << 2;
+        if (f.vy0 && f.vx0) d00 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + ko), d00);
+        if (f.vy0 && f.vx1) d01 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + row + ko), d01);
+        if (f.vy1 && f.vx0) d10 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + ko), d10);
+        if (f.vy1 && f.vx1) d11 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + row + ko), d11);
+    }
+}
+
+template <typename Cfg, int NL>
+__global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
+    const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
+    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw)
+{
+    extern __shared__ __attribute__((aligned(16))) float vwin[];
+    constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, SLICE = Cfg::SLICE, P = TILE_P;
+    constexpr int NV = Cfg::NV, NSTAGE = Cfg::NSTAGE, LCH = SLICE / 2, RPP = Cfg::ROWS_PER_PASS;
+    static_assert(NV == 4 && LCH == 16, "lanes own 16 channels");
+    static_assert(Cfg::THREADS == TH * TW * 2, "every lane owns a (cell, 16-channel half)");
+    const int tid = threadIdx.x;
+    const int HS = M * D / SLICE;
+    const int64_t row = (int64_t)M * D;
+
+    bool equal = true;
+    for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
+    if (!equal) return;          // msda_bwd_value_tile has done all three gradients for such levels
+
+    const int Hq = (int)shapes[0], Wq = (int)shapes[1];
+    const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
+    const int units = per_level * HS * B, units8 = (units + 7) / 8;
+    const float fW = (float)Wq, fH = (float)Hq;
+
+    const int sub = tid & 1, qi = tid >> 1, qly = qi / TW, qlx = qi % TW;
+    const int rot = (qlx / Cfg::TOK_PER_BANKROW) & (NV - 1);          // see msda_tile_body.h: LDS bank spreading
+    const int lane_off = sub * LCH;
+    // window copy: thread moves float4 `my_part` of window column `my_col`, rows my_row0 + i * RPP
+    const int my_part = tid % Cfg::PARTS, my_slot = tid / Cfg::PARTS;
+    const int my_row0 = my_slot / WW, my_col = my_slot % WW;
+    const bool col_ok = my_row0 < RPP;
+    float *const st_dst = vwin + (my_row0 * WW + my_col) * SLICE + my_part * 4;
+
+    // t enumerates xcd x (unit of that xcd) x query level: the L query levels (cameras) of one (tile, slice) run
+    // back to back on one XCD, so all but the first find the source windows in that L2 (as in msda_tile_body.h)
+    for (int t = blockIdx.x; t < units8 * 8 * L; t += gridDim.x) {
+        const int xcd = t & 7, r = t >> 3;
+        const int lq = r % L, unit = xcd * units8 + r / L;
+        if (r / L >= units8 || unit >= units) continue;
+        const int hs = unit % HS, u2 = unit / HS;
+        const int tin = u2 % per_level, b = u2 / per_level;
+        const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
+        const int ch0 = hs * SLICE + lane_off, head = ch0 / D;
+        const int qy = Y0 + qly, qx = X0 + qlx;
+        const bool active = qy < Hq && qx < Wq;
+        const int64_t q = (int64_t)b * S + lsi[lq] + (active ? (int64_t)qy * Wq + qx : 0);
+        const int64_t e0 = (q * M + head) * L * P;            // this (query, head)'s first tap
+        const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
+        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+        const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
+
+        float4 g[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const float4 *>(go + q * row + ch0 + ((k ^ rot) << 2));
+        // the (query, head)'s gradients of all levels stay in registers and leave as one contiguous run at the end:
+        // written level by level they would be 16/32-byte pieces 112/224 bytes apart, i.e. partial-line writes
+        float4 r_aw[NL], r_l0[NL], r_l1[NL];
+
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            if (l >= L) continue;                             // (uniform; `break` would keep the loop from unrolling)
+            __syncthreads();                                  // everyone is done reading the old window
+            {
+                const int gx = ox + my_col;
+                const bool xok = col_ok && (unsigned)gx < (unsigned)Wq;
+                const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
+                float4 stage[NSTAGE];
+#pragma unroll
+                for (int i = 0; i < NSTAGE; ++i) {
+                    const int wy = RPP == 1 ? i : my_row0 + i * RPP;
+                    const int gy = oy + wy;
+                    stage[i] = make_float4(0, 0, 0, 0);
+                    if (xok && wy < WH && (unsigned)gy < (unsigned)Hq)
+                        stage[i] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * Wq * row);
+                }
+                if (col_ok) {
+#pragma unroll
+                    for (int i = 0; i < NSTAGE; ++i)
+                        if ((RPP == 1 ? i : my_row0 + i * RPP) < WH)
+                            *reinterpret_cast<float4 *>(st_dst + i * RPP * WW * SLICE) = stage[i];
+                }
+            }
+            const float4 la = *reinterpret_cast<const float4 *>(loc + (e0 + l * P) * 2);
+            const float4 lb = *reinterpret_cast<const float4 *>(loc + (e0 + l * P) * 2 + 4);
+            const float4 wa = *reinterpret_cast<const float4 *>(aw + e0 + l * P);
+            __syncthreads();
+
+            const float xs[4] = {la.x * fW - 0.5f, la.z * fW - 0.5f, lb.x * fW - 0.5f, lb.z * fW - 0.5f};
+            const float ys[4] = {la.y * fH - 0.5f, la.w * fH - 0.5f, lb.y * fH - 0.5f, lb.w * fH - 0.5f};
+            const float as[4] = {wa.x, wa.y, wa.z, wa.w};
+            float ga[4], gx[4], gy[4];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float x = xs[p], y = ys[p];
+                f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
+                if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
+                    const int ix = (int)floorf(x) - ox, iy = (int)floorf(y) - oy;
+                    const float *p00 = vwin + __mul24(iy * WW + ix, SLICE) + lane_off;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        const float *pk = p00 + ((k ^ rot) << 2);
+                        q00 = dot4(g[k], *reinterpret_cast<const float4 *>(pk), q00);
+                        q01 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + SLICE), q01);
+                        q10 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * SLICE), q10);
+                        q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * SLICE + SLICE), q11);
+                    }
+                } else if (y > -1.f && x > -1.f && y < fH && x < fW) {
+                    corners_from_memory<NV>(vbatch + lsi[l] * row + lane_off, row, Hq, Wq, x, y, rot, g, q00, q01, q10, q11);
+                }
+                float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+                if constexpr (D > LCH) {                      // the other half of the head sits in the neighbouring lane
+                    d00 += __shfl_xor(d00, 1, 64);
+                    d01 += __shfl_xor(d01, 1, 64);
+                    d10 += __shfl_xor(d10, 1, 64);
+                    d11 += __shfl_xor(d11, 1, 64);
+                }
+                const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
+                ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
+                gx[p] = in_image ? fW * as[p] * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+                gy[p] = in_image ? fH * as[p] * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                __builtin_amdgcn_sched_barrier(0);            // one tap's 16 LDS reads in flight at a time
+            }
+            r_aw[l] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+            r_l0[l] = make_float4(gx[0], gy[0], gx[1], gy[1]);
+            r_l1[l] = make_float4(gx[2], gy[2], gx[3], gy[3]);
+        }
+        if (active && (D == LCH || sub == 0)) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                if (l >= L) continue;
+                *reinterpret_cast<float4 *>(grad_aw + e0 + l * P) = r_aw[l];
+                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2) = r_l0[l];
+                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2 + 4) = r_l1[l];
+            }
+        }
+    }
+}
+
+using SWide16 = TileCfg<16, 32, 8, 16, 6>;
+using SWide32 = TileCfg<32, 32, 8, 16, 6>;
+
+template <typename Cfg, int NL>
+static int launch_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
+                                float *grad_loc, float *grad_aw)
+{
+    static int blocks = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_tile<Cfg, NL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        int dev = 0, cus = 256, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_sampling_tile<Cfg, NL>, Cfg::THREADS,
+                                                         Cfg::LDS_BYTES) != hipSuccess || per_cu < 1)
+            per_cu = 2;
+        return (cus * per_cu + 7) / 8 * 8;
+    }();
+    hipLaunchKernelGGL((msda_bwd_sampling_tile<Cfg, NL>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
+                       go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw);
+    return (int)hipGetLastError();
+}
+
+int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
+                                float *grad_loc, float *grad_aw)
+{
+#define SAMPLING_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw
+    if (D == 16) return L <= 8 ? launch_sampling_tile<SWide16, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide16, 16>(SAMPLING_ARGS);
+    if (D == 32) return L <= 8 ? launch_sampling_tile<SWide32, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide32, 16>(SAMPLING_ARGS);
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace mvdetr

@@ -19,40 +19,25 @@
 //   * taps that leave the window, and jobs whose bound is not finite, take the direct fp32-atomic path, so
 //     the result is right for any sampling locations.
 //
-// grad_sampling_loc / grad_attn_weight come from the generic kernel run without its value atomics.
-// Unequal level shapes are detected on the device; the launch then does the direct atomics itself.
+// grad_sampling_loc / grad_attn_weight come from msda_backward_sampling.hip (LDS-staged value windows).
+// Unequal level shapes are detected on the device; this launch then runs the lane-group backward for all three
+// gradients itself (msda_backward_lanes.h) and the sampling kernel stands down.
 //
 // Replaces (with msda_backward.hip) ms_deformable_col2im_cuda's grad_value accumulation
 // (multiview_detector/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-152,301-920).
 #include "common.h"
 #include "msda_tile.h"
+#include "msda_backward_lanes.h"
 #include <stdlib.h>
 #include <string.h>
 
 namespace mvdetr {
 
-// the four corners of one tap, 16 channels of one lane, straight to memory
-__device__ __forceinline__ void direct_tap(float *__restrict__ gv, const float *g, float a, float x, float y, int H,
-                                           int W, int64_t level_base, int64_t row)
-{
-    if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) return;
-    const Footprint<float> f = footprint(y, x, H, W);
-    float *p00 = gv + level_base + ((int64_t)f.y0 * W + f.x0) * row;
-    const float w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a, w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        if (f.vy0 && f.vx0) atomicAdd(p00 + k, w00 * g[k]);
-        if (f.vy0 && f.vx1) atomicAdd(p00 + row + k, w01 * g[k]);
-        if (f.vy1 && f.vx0) atomicAdd(p00 + (int64_t)W * row + k, w10 * g[k]);
-        if (f.vy1 && f.vx1) atomicAdd(p00 + (int64_t)W * row + row + k, w11 * g[k]);
-    }
-}
-
 template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_value_tile(
-    const float *__restrict__ go, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
-    const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M, int L,
-    float *__restrict__ grad_value)
+    const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
+    int L, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw)
 {
     extern __shared__ __attribute__((aligned(16))) int win[];        // [SLICE][NTOKP] fixed-point accumulators
     __shared__ float red[Cfg::THREADS / 64];
@@ -67,26 +52,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_value_tile(
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
     if (!equal) {
-        // not this kernel's case: every (query, head, 16-channel half) does its taps directly
-        const int halves = D / LCH;
-        const int64_t total = (int64_t)B * S * M * halves;
-        for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < total; i += (int64_t)gridDim.x * THREADS) {
-            const int hh = (int)(i % halves);
-            const int64_t bqm = i / halves;
-            const int m = (int)(bqm % M);
-            const int b = (int)(bqm / M / S);
-            float g[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) g[k] = go[bqm * D + hh * LCH + k];
-            for (int l = 0; l < L; ++l) {
-                const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-                for (int p = 0; p < P; ++p) {
-                    const int64_t t = (bqm * L + l) * P + p;
-                    direct_tap(grad_value, g, aw[t], loc[2 * t] * (float)W - 0.5f, loc[2 * t + 1] * (float)H - 0.5f, H, W,
-                               ((int64_t)b * S + lsi[l]) * row + (int64_t)m * D + hh * LCH, row);
-                }
-            }
-        }
+        // not this kernel's case: the lane-group backward (msda_backward_lanes.h) does all three gradients here,
+        // and msda_bwd_sampling_tile, which sees the same shapes, stands down
+        const int64_t total = (int64_t)B * S * M * D;
+        for (int64_t base = (int64_t)blockIdx.x * THREADS; base < total; base += (int64_t)gridDim.x * THREADS)
+            msda_bwd_lanes_body<float, 1, D, true>(base + tid, go, value, shapes, lsi, loc, aw, B, S, M, D, L, S, P,
+                                                   grad_value, grad_loc, grad_aw);
         return;
     }
 
@@ -296,8 +267,9 @@ using BWide16 = TileCfg<16, 32, 6, 16, 6, 256>;
 using BWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 
 template <typename Cfg>
-static int launch_value_tile(hipStream_t st, const float *go, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                             const float *aw, int B, int S, int M, int L, float *grad_value)
+static int launch_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                             const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
+                             float *grad_value, float *grad_loc, float *grad_aw)
 {
     constexpr int LDS = (Cfg::SLICE + 2) * ((Cfg::WH * Cfg::WW) | 1) * 4;      // accumulators + weight mass
     static int blocks = [] {
@@ -312,16 +284,17 @@ static int launch_value_tile(hipStream_t st, const float *go, const int64_t *sha
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    hipLaunchKernelGGL((msda_bwd_value_tile<Cfg>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, go, shapes, lsi, loc,
-                       aw, B, S, M, L, grad_value);
+    hipLaunchKernelGGL((msda_bwd_value_tile<Cfg>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, go, value, shapes,
+                       lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw);
     return (int)hipGetLastError();
 }
 
-int msda_backward_value_tile(hipStream_t st, const float *go, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                             const float *aw, int B, int S, int M, int D, int L, float *grad_value)
+int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                             const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
+                             float *grad_value, float *grad_loc, float *grad_aw)
 {
-    if (D == 16) return launch_value_tile<BWide16>(st, go, shapes, lsi, loc, aw, B, S, M, L, grad_value);
-    if (D == 32) return launch_value_tile<BWide32>(st, go, shapes, lsi, loc, aw, B, S, M, L, grad_value);
+    if (D == 16) return launch_value_tile<BWide16>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw);
+    if (D == 32) return launch_value_tile<BWide32>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw);
     return (int)hipErrorInvalidValue;
 }
 

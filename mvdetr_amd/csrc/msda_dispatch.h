@@ -33,8 +33,14 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
                             int M, int D, int L, float *out);
 
 // grad_value of encoder-shaped fp32 calls through fixed-point LDS windows (msda_backward_tile.hip)
-int msda_backward_value_tile(hipStream_t st, const float *go, const int64_t *shapes, const int64_t *lsi, const float *loc,
-                             const float *aw, int B, int S, int M, int D, int L, float *grad_value);
+int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                             const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
+                             float *grad_value, float *grad_loc, float *grad_aw);
+
+// grad_sampling_loc / grad_attn_weight of the same calls from LDS-staged value windows (msda_backward_sampling.hip)
+int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
+                                float *grad_loc, float *grad_aw);
 
 template <typename T>
 inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *aw, const T *out, int B,
