@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 3
+#define MVDETR_OPS_ABI_VERSION 4
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -144,6 +144,17 @@ int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, co
 int mvdetr_warp_perspective_backward_f64(void *stream, const double *grad_dst, const double *M,
                                          int n, int channels, int src_h, int src_w, int dst_h,
                                          int dst_w, int layout_nhwc, double *grad_src);
+
+/* ---- Residual add + LayerNorm (the tail of both halves of the shadow transformer's encoder layer) -------
+ * Replaces  self.norm1(src + self.dropout1(src2))  /  self.norm2(src + self.dropout3(ffn))  in eval mode
+ * (multiview_detector/models/deformable_transformer.py:96-100; torch.nn.LayerNorm over the last dimension,
+ * biased variance, eps inside the square root) by one pass:
+ *     out[r, :] = LayerNorm(x[r, :] + residual[r, :]) * weight + bias
+ *   x, residual, out [rows, cols] fp32, contiguous (residual may be NULL; out must not overlap the inputs)
+ *   weight, bias     [cols]  (both NULL: no affine)
+ * cols must be 64, 128 or 256 with (cols/64)*4-byte aligned pointers: hipErrorNotSupported (801) otherwise. */
+int mvdetr_add_layernorm_f32(void *stream, const float *x, const float *residual, const float *weight,
+                             const float *bias, int64_t rows, int cols, float eps, float *out);
 
 /* ---- Introspection (used by bench.py / tests, not by the model code) ---------------------------
  * Name of the kernel variant the last forward call ON THIS THREAD dispatched to

@@ -12,3 +12,4 @@ from . import MultiScaleDeformableAttention as _msda_ext
 _sys.modules.setdefault("MultiScaleDeformableAttention", _msda_ext)
 
 from .warp import warp_perspective, WarpPerspectiveFunction  # noqa: E402,F401
+from .add_layernorm import add_layer_norm  # noqa: E402,F401

@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .ops.add_layernorm import add_layer_norm, fused_add_layer_norm_available
 from .ops.modules import MSDeformAttn
 
 
@@ -75,6 +76,15 @@ class DeformableTransformerEncoderLayer(nn.Module):
         attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
                               level_start_index, padding_mask, query_levels=query_levels,
                               projected_value=projected_value)
+        # eval mode on the GPU: residual add + LayerNorm in one HIP pass (dropout is the identity there);
+        # training keeps the reference's differentiable torch ops
+        if not self.training and fused_add_layer_norm_available(src, self.norm1):
+            src = add_layer_norm(attn, src, self.norm1)
+            # bias + ReLU in the GEMM's epilogue (hipBLASLt) instead of a separate pass over [tokens, d_ffn]
+            hidden = torch._addmm_activation(self.linear1.bias, src.flatten(0, -2), self.linear1.weight.t(),
+                                             use_gelu=False).view(*src.shape[:-1], -1) \
+                if hasattr(torch, "_addmm_activation") else F.relu(self.linear1(src))
+            return add_layer_norm(self.linear2(hidden), src, self.norm2)
         src = self.norm1(src + self.dropout1(attn))
         ffn = self.linear2(self.dropout2(F.relu(self.linear1(src))))
         return self.norm2(src + self.dropout3(ffn))
