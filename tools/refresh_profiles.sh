@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round-end measurement refresh on the GPU box: the default bench line, its rocprofv3 summaries, the microbenchmarks
+# (forward / backward / warp) and their kernel trace.  Everything lands in gpurun_out/profile_<tag>/.
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/profile_$TAG; mkdir -p $O; cd $R
+python bench.py 2> $O/bench_stderr.log | tail -1 > $O/${TAG}_bench.json
+cat $O/${TAG}_bench.json
+bash tools/profile_bench.sh $TAG > $O/profile_bench.log 2>&1
+(python tools/microbench.py --iters 30; python tools/microbench.py --iters 10 --config multiviewx; python tools/microbench.py --iters 5 --config stress16) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_microbench.txt
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $O/mb_trace -o t -- python $R/tools/microbench.py --iters 10 > /dev/null 2>&1
+cd $R; python tools/rocpd_summary.py $O/mb_trace/t_results.db --filter mvdetr > $O/${TAG}_microbench_kernel_stats.txt
+rm -rf $O/mb_trace
+cat $O/${TAG}_microbench.txt; cat $O/${TAG}_traffic.json
