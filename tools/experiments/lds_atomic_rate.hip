@@ -28,6 +28,12 @@ __global__ __launch_bounds__(256) void k(float *out, const int *tok, int iters)
             } else if (MODE == 6) {         // 64-bit integer atomics, lanes = queries at random tokens
                 a = (((tok[(it * 8 + u) * 4 + (lane & 3)] + lane) * 32 + u * 2) & 16382);
                 __hip_atomic_fetch_add(&win64[a >> 1], (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (MODE == 7) {         // 64-bit integer atomics, consecutive qwords (conflict-free)
+                a = (((it * 8 + u) * 64 + lane) * 2) & 16382;
+                __hip_atomic_fetch_add(&win64[a >> 1], (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (MODE == 8) {         // 32-bit integer atomics, consecutive dwords
+                a = ((it * 8 + u) * 64 + lane) & 16383;
+                __hip_atomic_fetch_add(reinterpret_cast<int *>(&win[a]), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else if (MODE == 3) {            // read-modify-write without atomics, same addresses as MODE 1
                 a = ((r * 32) + (lane & 15) + ((lane >> 4) & 1) * 16) & 16383;
                 win[a] += v;
@@ -77,5 +83,7 @@ int main()
     run<4>("ds_add_u32 4x16-channel groups, random", d_out, d_tok);
     run<5>("ds_add_u32 lanes = random tokens, 1 chan", d_out, d_tok);
     run<6>("ds_add_u64 lanes = random tokens", d_out, d_tok);
+    run<7>("ds_add_u64 consecutive qwords", d_out, d_tok);
+    run<8>("ds_add_u32 consecutive dwords", d_out, d_tok);
     return 0;
 }
