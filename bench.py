@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="frames per step per rank (dp mode; the reference only supports 1)")
     ap.add_argument("--augment", action="store_true", help="random affine augmentation matrices instead of identity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="keep hipBLASLt's default solution per GEMM instead of PyTorch TunableOp's measured pick")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--msda-impl", default="auto", choices=["auto", "gather", "tile"])
     return ap.parse_args()
@@ -161,7 +163,18 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP kernels have no CPU fallback)")
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = True      # the reference's own setting (main.py:48): MIOpen picks convolutions by measurement
+    if not a.no_gemm_tuning:
+        # the same for the shadow transformer's fp32 GEMMs: TunableOp times the hipBLASLt / rocBLAS solutions of each
+        # shape once (during the warm-up steps) and keeps the fastest; same arithmetic type, nothing is written to disk
+        try:
+            import tempfile
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_{os.getpid()}.csv"))
+            torch.cuda.tunable.write_file_on_exit(False)
+            torch.cuda.tunable.set_max_tuning_duration(200)
+        except Exception as ex:                    # pragma: no cover
+            print(f"[bench] TunableOp unavailable: {ex}", file=sys.stderr)
 
     import mvdetr_amd.ops  # noqa: F401
     import MultiScaleDeformableAttention as MSDA
@@ -242,7 +255,7 @@ def main():
                                f"{N}x3x{Hi}x{Wi} -> {geom.feat_channels}-ch world feat {geom.Rworld_shape[0]}x{geom.Rworld_shape[1]} "
                                f"-> BEV (BASELINE.json configs[1])" if a.config == "wildtrack" else f"{a.config} {N}-cam frame",
                    "frames_per_step": frames_per_step, "batch_per_rank": Bf, "parallelism": f"{a.parallel}{world}" + (f"-{a.encoder}" if a.parallel == "views" and world > 1 else ""),
-                   "augment": bool(a.augment),
+                   "augment": bool(a.augment), "gemm_tuning": not a.no_gemm_tuning,
                    "weights": "seeded random"},
         "roofline": {"bound": "hbm", "kernel": f"msda_forward[{impl}]", "achieved": round(achieved, 1) if achieved else None,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4) if achieved else None,
