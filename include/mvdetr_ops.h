@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 4
+#define MVDETR_OPS_ABI_VERSION 5
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -155,6 +155,12 @@ int mvdetr_warp_perspective_backward_f64(void *stream, const double *grad_dst, c
  * cols must be 64, 128 or 256 with (cols/64)*4-byte aligned pointers: hipErrorNotSupported (801) otherwise. */
 int mvdetr_add_layernorm_f32(void *stream, const float *x, const float *residual, const float *weight,
                              const float *bias, int64_t rows, int cols, float eps, float *out);
+/* The same with a second output  out2[r, :] = out[r, :] + add2[r % add2_rows, :]  -- the next encoder layer's query
+ * `src + pos` (deformable_transformer.py:92, with_pos_embed), so that add is not a pass of its own.  add2
+ * [add2_rows, cols] (the position embedding, shared by the batch); add2 and out2 are given together. */
+int mvdetr_add_layernorm_add_f32(void *stream, const float *x, const float *residual, const float *weight,
+                                 const float *bias, const float *add2, int64_t add2_rows, int64_t rows, int cols,
+                                 float eps, float *out, float *out2);
 
 /* ---- Introspection (used by bench.py / tests, not by the model code) ---------------------------
  * Name of the kernel variant the last forward call ON THIS THREAD dispatched to

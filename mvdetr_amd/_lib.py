@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
@@ -37,6 +37,7 @@ SIGNATURES = {
     "mvdetr_msda_backward_f32": (_MSDA_BWD, _i),
     "mvdetr_msda_backward_f64": (_MSDA_BWD, _i),
     "mvdetr_add_layernorm_f32": ([_vp] * 5 + [ctypes.c_int64, _i, ctypes.c_float, _vp], _i),
+    "mvdetr_add_layernorm_add_f32": ([_vp] * 6 + [ctypes.c_int64, ctypes.c_int64, _i, ctypes.c_float, _vp, _vp], _i),
     "mvdetr_warp_perspective_forward_f32": (_WARP, _i),
     "mvdetr_warp_perspective_forward_f64": (_WARP, _i),
     "mvdetr_warp_perspective_backward_f32": (_WARP, _i),

@@ -14,7 +14,9 @@ namespace mvdetr {
 template <int VEC>
 __global__ __launch_bounds__(256) void add_layernorm_rows(const float *__restrict__ x, const float *__restrict__ res,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          int64_t rows, float eps, float *__restrict__ out)
+                                                          const float *__restrict__ add2, int64_t add2_rows,
+                                                          int64_t rows, float eps, float *__restrict__ out,
+                                                          float *__restrict__ out2)
 {
     constexpr int COLS = VEC * 64;
     const int lane = threadIdx.x & 63;
@@ -48,6 +50,12 @@ __global__ __launch_bounds__(256) void add_layernorm_rows(const float *__restric
             y.v[i] = gamma ? n * g.v[i] + bt.v[i] : n;
         }
         y.store(out + r * COLS + lane * VEC);
+        if (out2) {                                           // second output: y + add2 (rows of add2 repeat)
+            const Pack<float, VEC> p = Pack<float, VEC>::load(add2 + (r % add2_rows) * COLS + lane * VEC);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) y.v[i] += p.v[i];
+            y.store(out2 + r * COLS + lane * VEC);
+        }
     }
 }
 
@@ -56,20 +64,28 @@ __global__ __launch_bounds__(256) void add_layernorm_rows(const float *__restric
 extern "C" int mvdetr_add_layernorm_f32(void *stream, const float *x, const float *residual, const float *weight,
                                         const float *bias, int64_t rows, int cols, float eps, float *out)
 {
+    return mvdetr_add_layernorm_add_f32(stream, x, residual, weight, bias, nullptr, 0, rows, cols, eps, out, nullptr);
+}
+
+extern "C" int mvdetr_add_layernorm_add_f32(void *stream, const float *x, const float *residual, const float *weight,
+                                            const float *bias, const float *add2, int64_t add2_rows, int64_t rows,
+                                            int cols, float eps, float *out, float *out2)
+{
     using namespace mvdetr;
     if (rows < 0 || cols <= 0) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     if (!x || !out || (weight == nullptr) != (bias == nullptr)) return (int)hipErrorInvalidValue;
+    if ((add2 == nullptr) != (out2 == nullptr) || (add2 && add2_rows <= 0)) return (int)hipErrorInvalidValue;
     if (cols != 64 && cols != 128 && cols != 256) return (int)hipErrorNotSupported;
     const size_t al = cols == 64 ? 4 : cols == 128 ? 8 : 16;
     if (!aligned(x, al) || !aligned(out, al) || (residual && !aligned(residual, al)) || (weight && !aligned(weight, al)) ||
-        (bias && !aligned(bias, al)))
+        (bias && !aligned(bias, al)) || (add2 && (!aligned(add2, al) || !aligned(out2, al))))
         return (int)hipErrorNotSupported;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t want = (rows + 3) / 4;
     const unsigned blocks = (unsigned)(want < 256 * 16 ? want : 256 * 16);         // grid-stride above 16 blocks per CU
-    if (cols == 64) hipLaunchKernelGGL(add_layernorm_rows<1>, dim3(blocks), dim3(256), 0, st, x, residual, weight, bias, rows, eps, out);
-    else if (cols == 128) hipLaunchKernelGGL(add_layernorm_rows<2>, dim3(blocks), dim3(256), 0, st, x, residual, weight, bias, rows, eps, out);
-    else hipLaunchKernelGGL(add_layernorm_rows<4>, dim3(blocks), dim3(256), 0, st, x, residual, weight, bias, rows, eps, out);
+    if (cols == 64) hipLaunchKernelGGL(add_layernorm_rows<1>, dim3(blocks), dim3(256), 0, st, x, residual, weight, bias, add2, add2_rows, rows, eps, out, out2);
+    else if (cols == 128) hipLaunchKernelGGL(add_layernorm_rows<2>, dim3(blocks), dim3(256), 0, st, x, residual, weight, bias, add2, add2_rows, rows, eps, out, out2);
+    else hipLaunchKernelGGL(add_layernorm_rows<4>, dim3(blocks), dim3(256), 0, st, x, residual, weight, bias, add2, add2_rows, rows, eps, out, out2);
     return (int)hipGetLastError();
 }

@@ -69,11 +69,13 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, *,
-                query_levels=None, projected_value=None):
+                query_levels=None, projected_value=None, query=None, next_pos=None):
         """deformable_transformer.py:88-100.  With ``projected_value`` (self_attn.project_value of ALL tokens)
         ``src``/``pos``/``reference_points`` may hold only the queries of levels ``query_levels`` -- one rank's
-        share of a query-sharded layer (mvdetr_amd/dist.py); the layer is per-token apart from the attention."""
-        attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
+        share of a query-sharded layer (mvdetr_amd/dist.py); the layer is per-token apart from the attention.
+        ``query``: ``src + pos`` if the caller already has it; ``next_pos``: also return ``output + next_pos`` (the
+        next layer's query) -- the encoder uses both to fold the position add into the LayerNorm pass."""
+        attn = self.self_attn(self.with_pos_embed(src, pos) if query is None else query, reference_points, src, spatial_shapes,
                               level_start_index, padding_mask, query_levels=query_levels,
                               projected_value=projected_value)
         # eval mode on the GPU: residual add + LayerNorm in one HIP pass (dropout is the identity there);
@@ -84,10 +86,11 @@ class DeformableTransformerEncoderLayer(nn.Module):
             hidden = torch._addmm_activation(self.linear1.bias, src.flatten(0, -2), self.linear1.weight.t(),
                                              use_gelu=False).view(*src.shape[:-1], -1) \
                 if hasattr(torch, "_addmm_activation") else F.relu(self.linear1(src))
-            return add_layer_norm(self.linear2(hidden), src, self.norm2)
+            return add_layer_norm(self.linear2(hidden), src, self.norm2, then_add=next_pos)
         src = self.norm1(src + self.dropout1(attn))
         ffn = self.linear2(self.dropout2(F.relu(self.linear1(src))))
-        return self.norm2(src + self.dropout3(ffn))
+        out = self.norm2(src + self.dropout3(ffn))
+        return out if next_pos is None else (out, out + next_pos)
 
 
 class DeformableTransformerEncoder(nn.Module):
@@ -106,9 +109,13 @@ class DeformableTransformerEncoder(nn.Module):
                              "default of Deformable-DETR is not part of this contract "
                              "(ms_deform_attn.py:104-107)")
         ref = self.reference_points.unsqueeze(0).expand(src.shape[0], -1, -1, -1, -1)
-        out = src
-        for layer in self.layers:
-            out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask)
+        out, query = src, None
+        for i, layer in enumerate(self.layers):
+            if pos is not None and i + 1 < self.num_layers:
+                out, query = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask, query=query,
+                                   next_pos=pos)                 # the next layer's src + pos comes with the LayerNorm
+            else:
+                out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask, query=query)
         return out
 
 

@@ -68,3 +68,42 @@ def test_encoder_layer_eval_uses_the_fused_tail_and_matches_training_mode_ops():
     src_g = src.clone().requires_grad_(True)                # grad mode: the torch formulation
     plain = layer(src_g, pos, ref, shapes, lsi)
     assert (fused - plain.detach()).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("batch_pos", [False, True])
+def test_add_layer_norm_second_output(batch_pos):
+    from mvdetr_amd.ops.add_layernorm import add_layer_norm
+    g = torch.Generator().manual_seed(3)
+    x, res = torch.randn(2, 501, 128, generator=g).cuda(), torch.randn(2, 501, 128, generator=g).cuda()
+    pos = torch.randn(2 if batch_pos else 1, 501, 128, generator=g).cuda()
+    norm = torch.nn.LayerNorm(128).cuda()
+    with torch.no_grad():
+        y, y2 = add_layer_norm(x, res, norm, then_add=pos)
+        want = norm(x + res)
+    assert (y - want).abs().max().item() < 5e-6
+    assert (y2 - (want + pos)).abs().max().item() < 5e-6
+    # torch path (autograd needed) returns the same pair
+    xg = x.clone().requires_grad_(True)
+    z, z2 = add_layer_norm(xg, res, norm, then_add=pos)
+    assert (z.detach() - y).abs().max().item() < 5e-6 and (z2.detach() - y2).abs().max().item() < 5e-6
+
+
+def test_encoder_folds_position_add_and_matches_layer_by_layer():
+    """DeformableTransformerEncoder passes each layer's `output + pos` on as the next layer's query; the result is
+    the plain layer-by-layer evaluation's."""
+    from mvdetr_amd.world_feat import DeformTransWorldFeat
+    torch.manual_seed(1)
+    N, H, W, C = 3, 16, 24, 128
+    h, w = H // 2, W // 2
+    ys, xs = torch.meshgrid(torch.arange(h) + 0.5, torch.arange(w) + 0.5, indexing="ij")
+    ref = torch.stack([xs / w, ys / h], -1).reshape(1, h * w, 1, 1, 2).repeat(N, 1, N, 4, 1).view(-1, N, 4, 2)
+    wf = DeformTransWorldFeat(N, (H, W), C, hidden_dim=C, reference_points=ref).cuda().eval()
+    tokens = torch.randn(2, N * h * w, C, device="cuda")
+    with torch.no_grad():
+        pos = wf.level_pos(h, w)
+        got = wf.encoder(tokens, wf.spatial_shapes, wf.level_start_index, None, pos)
+        out = tokens
+        refs = wf.encoder.reference_points.unsqueeze(0).expand(2, -1, -1, -1, -1)
+        for layer in wf.encoder.layers:
+            out = layer(out, pos, refs, wf.spatial_shapes, wf.level_start_index)
+    assert (got - out).abs().max().item() < 1e-5
