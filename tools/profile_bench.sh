@@ -9,7 +9,7 @@ TAG=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/profile_$TAG
 mkdir -p $O
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline $@"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-gemm-tuning $@"   # (tuning would fill the trace with candidate GEMMs)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench.py $ARGS > $O/bench_under_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $O/pmc_fetch -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_fetch.log 2>&1
