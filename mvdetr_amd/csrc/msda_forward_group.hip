@@ -35,7 +35,13 @@ __device__ __forceinline__ void gfma4(float2v &lo, float2v &hi, float w, const f
 
 // FUSED = false: `off` / `logit` hold final sampling locations / attention weights (the extension's public
 // contract, any SamplingLayout) and `ref` is unused.
-template <typename Cfg, int NG, int WAVES, bool FUSED>
+template <bool WIDE> struct MissMask { using type = unsigned; };
+template <> struct MissMask<true> { using type = unsigned long long; };
+
+// SPLIT > 1: the workgroup has SPLIT lane groups of TH*TW*2 lanes each; all use the same staged window, group g
+// takes the cameras [g*NGA, (g+1)*NGA) with NGA = ceil(NG/SPLIT) -- NGA accumulator sets per lane instead of NG,
+// which is what makes many-camera rigs (16 cameras: 4 groups x 4) fit the register file at all.
+template <typename Cfg, int NG, int WAVES, bool FUSED, int SPLIT = 1>
 __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
@@ -52,8 +58,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
 
     for (int l = 1; l < L; ++l)
         if (shapes[2 * l] != shapes[0] || shapes[2 * l + 1] != shapes[1]) {            // not ours (see header)
-            using Fallback = TileCfg<Cfg::D, 32, 8, 16, 6>;
-            static_assert(Fallback::THREADS == Cfg::THREADS, "the fallback body runs on this launch's workgroups");
+            using Fallback = TileCfg<Cfg::D, 32, 8, 16, 6, Cfg::THREADS>;
             msda_fwd_tile_body<Fallback, FUSED>(win, value, shapes, lsi, off, logit, ref, ref_bstride, lay,
                                                 QueryLevels{0, L, S}, B, S, M, L, out);
             return;
@@ -62,7 +67,15 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
     const int jobs = per_level * HS * B, jobs8 = (jobs + 7) / 8;
 
-    const int sub = tid & 1, qi = tid >> 1;
+    constexpr int GROUP_LANES = SPLIT == 1 ? Cfg::THREADS : TH * TW * 2;       // lanes of one camera group
+    static_assert(SPLIT == 1 || (GROUP_LANES % 64 == 0 && GROUP_LANES * SPLIT <= Cfg::THREADS), "whole waves per group");
+    constexpr int NGA = (NG + SPLIT - 1) / SPLIT;             // cameras (accumulator sets) per lane
+    using MissT = typename MissMask<(NG * TILE_P > 32)>::type;    // one bit per (level, point)
+    const int grp = SPLIT == 1 ? 0 : tid / GROUP_LANES;       // wave-uniform
+    const int ltid = tid - grp * GROUP_LANES;
+    const int cam0 = grp * NGA;
+    const int ncam = grp >= SPLIT ? 0 : (NG - cam0 < NGA ? (NG - cam0 < 0 ? 0 : NG - cam0) : NGA);
+    const int sub = ltid & 1, qi = ltid >> 1;
     const int qly = qi / TW, qlx = qi % TW;
     const int rot = (qlx / Cfg::TOK_PER_BANKROW) & (NV - 1);
     const int lane_off = sub * LCH;
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         const int ch0 = hs * SLICE + lane_off;
         const int head = ch0 / D, ch_off = ch0 % D;
         const int qy = Y0 + qly, qx = X0 + qlx;
-        const bool active = qi < TH * TW && qy < Hq && qx < Wq;
+        const bool active = ncam > 0 && qi < TH * TW && qy < Hq && qx < Wq;
         // per-lane part of the sampling-data addresses (cell, head); camera c adds (b*S + lsi[c]) queries
         const int64_t cell = active ? (int64_t)qy * Wq + qx : 0;
         const float *lp0 = off + cell * lay.q_l + head * lay.h_l;
@@ -90,16 +103,16 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         auto cam_q = [&](int c) { return (int64_t)b * S + lsi[c]; };          // wave-uniform
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
 
-        float2v acc[NG][2 * NV];
-        float smax[NG], ssum[NG];
-        unsigned miss[NG];
+        float2v acc[NGA][2 * NV];
+        float smax[NGA], ssum[NGA];
+        MissT miss[NGA];
 #pragma unroll
-        for (int c = 0; c < NG; ++c) {
+        for (int c = 0; c < NGA; ++c) {
 #pragma unroll
             for (int i = 0; i < 2 * NV; ++i) acc[c][i] = (float2v){0.f, 0.f};
             smax[c] = -INFINITY;
             ssum[c] = 0.f;
-            miss[c] = 0u;
+            miss[c] = 0;
         }
 
         for (int l = 0; l < L; ++l) {
@@ -112,20 +125,27 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                 const int gx = ox + my_col;
                 const bool xok = col_ok && (unsigned)gx < (unsigned)Wq;
                 const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
-                float4 stage[NSTAGE];
+                // SPLIT > 1 runs at 3 waves / SIMD (168 VGPRs): the column goes through the registers in chunks
+                constexpr int CHUNK = SPLIT == 1 ? NSTAGE : 6;
 #pragma unroll
-                for (int i = 0; i < NSTAGE; ++i) {
-                    const int wy = RPP == 1 ? i : my_row0 + i * RPP;       // RPP == 1: scalar row arithmetic
-                    const int gy = oy + wy;
-                    stage[i] = make_float4(0, 0, 0, 0);
-                    if (xok && wy < WH && (unsigned)gy < (unsigned)Hq)
-                        stage[i] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * Wq * row);
-                }
-                if (col_ok) {
+                for (int i0 = 0; i0 < NSTAGE; i0 += CHUNK) {
+                    float4 stage[CHUNK];
 #pragma unroll
-                    for (int i = 0; i < NSTAGE; ++i)
-                        if ((RPP == 1 ? i : my_row0 + i * RPP) < WH)
-                            *reinterpret_cast<float4 *>(st_dst + i * RPP * WW * SLICE) = stage[i];
+                    for (int j = 0; j < CHUNK; ++j) {
+                        const int i = i0 + j;
+                        const int wy = RPP == 1 ? i : my_row0 + i * RPP;       // RPP == 1: scalar row arithmetic
+                        const int gy = oy + wy;
+                        stage[j] = make_float4(0, 0, 0, 0);
+                        if (i < NSTAGE && xok && wy < WH && (unsigned)gy < (unsigned)Hq)
+                            stage[j] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * Wq * row);
+                    }
+                    if (col_ok) {
+#pragma unroll
+                        for (int j = 0; j < CHUNK; ++j)
+                            if (i0 + j < NSTAGE && (RPP == 1 ? i0 + j : my_row0 + (i0 + j) * RPP) < WH)
+                                *reinterpret_cast<float4 *>(st_dst + (i0 + j) * RPP * WW * SLICE) = stage[j];
+                    }
+                    if (CHUNK < NSTAGE) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
@@ -146,12 +166,13 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                         nrb = *reinterpret_cast<const float4 *>(rp + 4);
                     }
                 };
-                load_cam(0);
+                load_cam(cam0);
 #pragma unroll
-                for (int c = 0; c < NG; ++c) {
+                for (int c = 0; c < NGA; ++c) {
+                    if (c >= ncam) continue;                  // (wave-uniform)
                     float4 la = na, lb = nb, wa = nw;
                     const float4 ra = nra, rb = nrb;
-                    if (c + 1 < NG) load_cam(c + 1);
+                    if (c + 1 < ncam) load_cam(cam0 + c + 1);
                     float xs[4], ys[4];
                     if constexpr (FUSED) {
                         // fold this level's logits into camera c's running softmax
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                                 gfma4(acc[c][2 * k], acc[c][2 * k + 1], w11, c11);
                             }
                         } else {
-                            miss[c] |= 1u << (l * P + p);
+                            miss[c] |= (MissT)1 << (l * P + p);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -213,14 +234,15 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
 
         if (active) {
 #pragma unroll
-            for (int c = 0; c < NG; ++c) {
-                const int64_t cq = cam_q(c);
+            for (int c = 0; c < NGA; ++c) {
+                if (c >= ncam) continue;
+                const int64_t cq = cam_q(cam0 + c);
                 const float *lp = lp0 + cq * lay.q_l, *wp = wp0 + cq * lay.q_w;
-                const float *rp = FUSED ? rp0 + lsi[c] * L * P * 2 : nullptr;
-                unsigned mm = miss[c];
+                const float *rp = FUSED ? rp0 + lsi[cam0 + c] * L * P * 2 : nullptr;
+                MissT mm = miss[c];
                 // taps that left the window: straight from global memory (zero padding by test)
                 while (mm) {
-                    const int bit = __ffs((int)mm) - 1;
+                    const int bit = __ffsll((long long)mm) - 1;
                     mm &= mm - 1;
                     const int l = bit / P, pp = bit - l * P;
                     const float fW = (float)Wq, fH = (float)Hq;
@@ -270,8 +292,11 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
 // window columns.
 using GWide16 = TileCfg<16, 32, 6, 16, 6, 256>;
 using GWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
+// many cameras: 4 lane groups of 3 waves on one window, 4 cameras each -- 768 threads, one workgroup per CU
+using GQuad16 = TileCfg<16, 32, 6, 16, 6, 768>;
+using GQuad32 = TileCfg<32, 32, 6, 16, 6, 768>;
 
-template <typename Cfg, int NG, int WAVES, bool FUSED>
+template <typename Cfg, int NG, int WAVES, bool FUSED, int SPLIT = 1>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
                         SamplingLayout lay, int B, int S, int M, float *out)
@@ -279,26 +304,27 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
     // dynamic LDS: the larger of this kernel's window and the fallback body's
     constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
                                                                                    : TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
+    auto kernel = &msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT>;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES, FUSED>, Cfg::THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT>, Cfg::THREADS,
                                                          LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    hipLaunchKernelGGL((msda_fwd_group<Cfg, NG, WAVES, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
     return (int)hipGetLastError();
 }
 
 bool msda_group_supported(int D, int L)
 {
     static const bool enabled = [] { const char *e = getenv("MVDETR_MSDA_GROUP"); return !(e && e[0] == '0'); }();
-    return enabled && (D == 16 || D == 32) && (L == 6 || L == 7);
+    return enabled && (D == 16 || D == 32) && (L == 6 || L == 7 || (L >= 9 && L <= 16));
 }
 
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -307,6 +333,18 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
 {
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out
     const bool fused = ref != nullptr;
+    if (L >= 9 && L <= 16) {           // many cameras: 4 lane groups x up to 4 cameras (NG is the template's loop bound)
+        switch ((D == 32 ? 100 : 0) + L) {
+#define QUAD_CASE(DD, LL, CFG)                                                                                       \
+        case DD + LL: return fused ? launch_group<CFG, LL, 3, true, 4>(GROUP_ARGS) : launch_group<CFG, LL, 3, false, 4>(GROUP_ARGS);
+        QUAD_CASE(0, 9, GQuad16) QUAD_CASE(0, 10, GQuad16) QUAD_CASE(0, 11, GQuad16) QUAD_CASE(0, 12, GQuad16)
+        QUAD_CASE(0, 13, GQuad16) QUAD_CASE(0, 14, GQuad16) QUAD_CASE(0, 15, GQuad16) QUAD_CASE(0, 16, GQuad16)
+        QUAD_CASE(100, 9, GQuad32) QUAD_CASE(100, 10, GQuad32) QUAD_CASE(100, 11, GQuad32) QUAD_CASE(100, 12, GQuad32)
+        QUAD_CASE(100, 13, GQuad32) QUAD_CASE(100, 14, GQuad32) QUAD_CASE(100, 15, GQuad32) QUAD_CASE(100, 16, GQuad32)
+#undef QUAD_CASE
+        default: break;
+        }
+    }
     if (D == 16 && L == 7) return fused ? launch_group<GWide16, 7, 2, true>(GROUP_ARGS) : launch_group<GWide16, 7, 2, false>(GROUP_ARGS);
     if (D == 16 && L == 6) return fused ? launch_group<GWide16, 6, 2, true>(GROUP_ARGS) : launch_group<GWide16, 6, 2, false>(GROUP_ARGS);
     if (D == 32 && L == 7) return fused ? launch_group<GWide32, 7, 2, true>(GROUP_ARGS) : launch_group<GWide32, 7, 2, false>(GROUP_ARGS);

@@ -115,7 +115,7 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
         // query index: token index minus the first token of the query levels (guarded against a caller whose
         // Lq is smaller than the levels it names)
         const int64_t q = lsi[lq] - q_first + (int64_t)qy * Wq + qx;
-        const bool active = qy < Hq && qx < Wq && q < Lq;
+        const bool active = qi < TH * TW && qy < Hq && qx < Wq && q < Lq;      // (surplus lanes only copy)
         const int64_t bqm = active ? (((int64_t)b * Lq + q) * M + head) : 0;
         // sampling data of this (query, head): element (query, head, level) of `loc` starts at
         // query * lay.q_l + head * lay.h_l + level * lay.l_l floats (`aw`: the *_w strides).  The reference

@@ -658,3 +658,33 @@ def test_backward_nonfinite_upstream_gradients_propagate_like_fp32_atomics(ops):
     clean[0, 5] = clean[1, 1] = False
     assert torch.isfinite(gv4[..., clean]).all()                       # ... and only they
     assert (gv4[..., clean].double() - ref4[..., clean]).abs().max().item() < 2e-4
+
+
+# ---- many cameras (9..16 levels): the camera-split group kernel (4 lane groups on one window) ------------------
+@pytest.mark.parametrize("L,D,M,H,W,B", [(9, 16, 8, 13, 21, 1), (12, 16, 4, 9, 33, 2), (16, 32, 8, 12, 20, 1), (13, 32, 2, 7, 18, 1)])
+def test_many_camera_group_kernel_fused_and_unfused(ops, msda_impl, L, D, M, H, W, B):
+    MSDA = msda_impl
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(L, H, W, M=M, D=D, B=B, seed=L, noise_px=1.5)
+    want = torch_oracle.msda_core(value, shapes, loc, aw)
+    got, used = _fwd_impl(MSDA, "tile", (value, shapes, lsi, loc, aw))
+    assert used == "tile"
+    assert (got - want).abs().max().item() < FP32_TOL
+    # fused entry on the same problem: raw offsets (pixels) and logits whose softmax is `aw`
+    S, P = value.shape[1], 4
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(1, H * W, 1, 1, 2).repeat(B, L, L, P, 1)
+    off = (loc - ref[:, :, None]) * torch.tensor([W, H], dtype=torch.float32)
+    logit = torch.log(aw.clamp_min(1e-30))
+    out = MSDA.ms_deform_attn_forward_fused(*dev(value, shapes, lsi, ref, off, logit)).cpu()
+    assert MSDA.last_forward_impl() == "tile_fused"
+    assert (out - want).abs().max().item() < FP32_TOL
+
+
+def test_many_unequal_levels_fall_back_inside_the_group_launch(ops, msda_impl):
+    from helpers import pyramid_encoder_inputs
+    MSDA = msda_impl
+    lv = [(12, 20), (6, 10), (12, 20), (3, 5), (8, 8), (12, 20), (5, 9), (4, 4), (9, 14), (2, 7)]
+    value, shapes, lsi, loc, aw = pyramid_encoder_inputs(lv, M=8, D=16, seed=4)
+    want = torch_oracle.msda_core(value, shapes, loc, aw)
+    got, used = _fwd_impl(MSDA, "tile", (value, shapes, lsi, loc, aw))
+    assert used == "tile" and (got - want).abs().max().item() < FP32_TOL
