@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 5
+#define MVDETR_OPS_ABI_VERSION 6
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -58,9 +58,12 @@ int mvdetr_msda_forward_f64(void *stream, const double *value, const int64_t *sp
  *                    `ref_batch_stride` floats apart (0 = one set shared by the whole batch)
  *   sampling_offsets [batch, num_query, num_heads, num_levels, num_point, 2]  (the Linear's raw output)
  *   attn_logits      [batch, num_query, num_heads, num_levels, num_point]     (the Linear's raw output)
- *   level_major != 0: the two raw tensors are [batch, num_query, num_levels, num_heads, num_point(, 2)]
- *                    instead -- the caller permutes the Linear's weight rows once; keeps what one level
- *                    iteration reads in the same cache lines
+ *   level_major      bit mask.  Bit 0 (1): the two raw tensors are [batch, num_query, num_levels, num_heads,
+ *                    num_point(, 2)] instead -- the caller permutes the Linear's weight rows once; keeps what one
+ *                    level iteration reads in the same cache lines.  Bit 1 (2): reference_points is
+ *                    [*, num_query, num_levels, 2], ONE point per (query, level) shared by the num_point sampling
+ *                    points -- what MVDeTr's reference map holds P copies of (mvdetr.py:49-58 with all heights 0);
+ *                    a quarter of the reference bytes.  Other bits: hipErrorInvalidValue.
  *   offsets_query_stride / logits_query_stride: floats from one query's block to the next (0 = dense), so
  *                    both may be column blocks of one wider GEMM output; multiples of 4
  * Only the shapes the LDS-tiled kernel takes are supported (fp32, channels 16 or 32, num_point 4,

@@ -29,7 +29,7 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
 // fused variant: reference points + raw offsets + raw logits (see msda_forward_tile.hip)
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
-                            int level_major, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
+                            int layout, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
                             int M, int D, int L, float *out);
 
 // grad_value of encoder-shaped fp32 calls through fixed-point LDS windows (msda_backward_tile.hip)

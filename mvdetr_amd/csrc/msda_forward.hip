@@ -207,18 +207,19 @@ int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const
         return (int)hipErrorInvalidValue;
     if (query_level_begin < 0 || query_level_end <= query_level_begin || query_level_end > num_levels)
         return (int)hipErrorInvalidValue;
+    if (level_major & ~3) return (int)hipErrorInvalidValue;             // bit 0 level-major raw tensors, bit 1 shared reference point
     if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !out)
         return (int)hipErrorInvalidValue;
     const bool a16 = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(reference_points) |
                        reinterpret_cast<uintptr_t>(sampling_offsets) | reinterpret_cast<uintptr_t>(attn_logits) |
-                       reinterpret_cast<uintptr_t>(out)) % 16) == 0 && ref_batch_stride % 4 == 0;
+                       reinterpret_cast<uintptr_t>(out)) % 16) == 0 && ref_batch_stride % ((level_major & 2) ? 2 : 4) == 0;
     if (!msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, a16,
                              query_level_begin, query_level_end))
         return (int)hipErrorNotSupported;
     g_last_impl = "tile_fused";
     return msda_forward_tile_fused(reinterpret_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
                                    reference_points, ref_batch_stride, sampling_offsets, attn_logits,
-                                   level_major ? 1 : 0, offsets_query_stride, logits_query_stride, query_level_begin,
+                                   level_major, offsets_query_stride, logits_query_stride, query_level_begin,
                                    query_level_end, num_query, batch, spatial_size, num_heads, channels, num_levels,
                                    out);
 }

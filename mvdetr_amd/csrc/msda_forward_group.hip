@@ -41,7 +41,7 @@ template <> struct MissMask<true> { using type = unsigned long long; };
 // SPLIT > 1: the workgroup has SPLIT lane groups of TH*TW*2 lanes each; all use the same staged window, group g
 // takes the cameras [g*NGA, (g+1)*NGA) with NGA = ceil(NG/SPLIT) -- NGA accumulator sets per lane instead of NG,
 // which is what makes many-camera rigs (16 cameras: 4 groups x 4) fit the register file at all.
-template <typename Cfg, int NG, int WAVES, bool FUSED, int SPLIT = 1>
+template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1>
 __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         const int64_t cell = active ? (int64_t)qy * Wq + qx : 0;
         const float *lp0 = off + cell * lay.q_l + head * lay.h_l;
         const float *wp0 = logit + cell * lay.q_w + head * lay.h_w;
-        const float *rp0 = FUSED ? ref + b * ref_bstride + cell * L * P * 2 : nullptr;
+        constexpr int RPL = FUSED == 2 ? 2 : P * 2;         // floats of reference points per (query, level)
+        const float *rp0 = FUSED ? ref + b * ref_bstride + cell * L * RPL : nullptr;
         auto cam_q = [&](int c) { return (int64_t)b * S + lsi[c]; };          // wave-uniform
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
 
@@ -160,10 +161,13 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     na = *reinterpret_cast<const float4 *>(lp);
                     nb = *reinterpret_cast<const float4 *>(lp + 4);
                     nw = *reinterpret_cast<const float4 *>(wp0 + cq * lay.q_w + l * lay.l_w);
-                    if constexpr (FUSED) {
+                    if constexpr (FUSED == 1) {
                         const float *rp = rp0 + (cq - (int64_t)b * S) * L * P * 2 + l * P * 2;
                         nra = *reinterpret_cast<const float4 *>(rp);
                         nrb = *reinterpret_cast<const float4 *>(rp + 4);
+                    } else if constexpr (FUSED == 2) {
+                        const float2 r = *reinterpret_cast<const float2 *>(rp0 + (cq - (int64_t)b * S) * L * 2 + l * 2);
+                        nra = nrb = make_float4(r.x, r.y, r.x, r.y);
                     }
                 };
                 load_cam(cam0);
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                 if (c >= ncam) continue;
                 const int64_t cq = cam_q(cam0 + c);
                 const float *lp = lp0 + cq * lay.q_l, *wp = wp0 + cq * lay.q_w;
-                const float *rp = FUSED ? rp0 + lsi[cam0 + c] * L * P * 2 : nullptr;
+                const float *rp = FUSED ? rp0 + lsi[cam0 + c] * L * RPL : nullptr;
                 MissT mm = miss[c];
                 // taps that left the window: straight from global memory (zero padding by test)
                 while (mm) {
@@ -248,8 +252,9 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     const float fW = (float)Wq, fH = (float)Hq;
                     float lx = lp[l * lay.l_l + pp * 2 + 0], ly = lp[l * lay.l_l + pp * 2 + 1], a = wp[l * lay.l_w + pp];
                     if constexpr (FUSED) {
-                        lx = rp[bit * 2 + 0] + lx * (1.f / fW);
-                        ly = rp[bit * 2 + 1] + ly * (1.f / fH);
+                        const int ri = FUSED == 2 ? l * 2 : bit * 2;
+                        lx = rp[ri + 0] + lx * (1.f / fW);
+                        ly = rp[ri + 1] + ly * (1.f / fH);
                         a = __expf(a - smax[c]);
                     }
                     const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
@@ -296,7 +301,7 @@ using GWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 using GQuad16 = TileCfg<16, 32, 6, 16, 6, 768>;
 using GQuad32 = TileCfg<32, 32, 6, 16, 6, 768>;
 
-template <typename Cfg, int NG, int WAVES, bool FUSED, int SPLIT = 1>
+template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
                         SamplingLayout lay, int B, int S, int M, float *out)
@@ -328,15 +333,15 @@ bool msda_group_supported(int D, int L)
 }
 
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
-                       const float *off, const float *logit, const float *ref, int64_t ref_bstride,
+                       const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out)
 {
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out
-    const bool fused = ref != nullptr;
     if (L >= 9 && L <= 16) {           // many cameras: 4 lane groups x up to 4 cameras (NG is the template's loop bound)
         switch ((D == 32 ? 100 : 0) + L) {
 #define QUAD_CASE(DD, LL, CFG)                                                                                       \
-        case DD + LL: return fused ? launch_group<CFG, LL, 3, true, 4>(GROUP_ARGS) : launch_group<CFG, LL, 3, false, 4>(GROUP_ARGS);
+        case DD + LL: return fused == 2 ? launch_group<CFG, LL, 3, 2, 4>(GROUP_ARGS) : fused ? launch_group<CFG, LL, 3, 1, 4>(GROUP_ARGS) \
+                                                                                        : launch_group<CFG, LL, 3, 0, 4>(GROUP_ARGS);
         QUAD_CASE(0, 9, GQuad16) QUAD_CASE(0, 10, GQuad16) QUAD_CASE(0, 11, GQuad16) QUAD_CASE(0, 12, GQuad16)
         QUAD_CASE(0, 13, GQuad16) QUAD_CASE(0, 14, GQuad16) QUAD_CASE(0, 15, GQuad16) QUAD_CASE(0, 16, GQuad16)
         QUAD_CASE(100, 9, GQuad32) QUAD_CASE(100, 10, GQuad32) QUAD_CASE(100, 11, GQuad32) QUAD_CASE(100, 12, GQuad32)
@@ -345,10 +350,10 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
         default: break;
         }
     }
-    if (D == 16 && L == 7) return fused ? launch_group<GWide16, 7, 2, true>(GROUP_ARGS) : launch_group<GWide16, 7, 2, false>(GROUP_ARGS);
-    if (D == 16 && L == 6) return fused ? launch_group<GWide16, 6, 2, true>(GROUP_ARGS) : launch_group<GWide16, 6, 2, false>(GROUP_ARGS);
-    if (D == 32 && L == 7) return fused ? launch_group<GWide32, 7, 2, true>(GROUP_ARGS) : launch_group<GWide32, 7, 2, false>(GROUP_ARGS);
-    if (D == 32 && L == 6) return fused ? launch_group<GWide32, 6, 2, true>(GROUP_ARGS) : launch_group<GWide32, 6, 2, false>(GROUP_ARGS);
+    if (D == 16 && L == 7) return fused == 2 ? launch_group<GWide16, 7, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide16, 7, 2, 1>(GROUP_ARGS) : launch_group<GWide16, 7, 2, 0>(GROUP_ARGS);
+    if (D == 16 && L == 6) return fused == 2 ? launch_group<GWide16, 6, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide16, 6, 2, 1>(GROUP_ARGS) : launch_group<GWide16, 6, 2, 0>(GROUP_ARGS);
+    if (D == 32 && L == 7) return fused == 2 ? launch_group<GWide32, 7, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide32, 7, 2, 1>(GROUP_ARGS) : launch_group<GWide32, 7, 2, 0>(GROUP_ARGS);
+    if (D == 32 && L == 6) return fused == 2 ? launch_group<GWide32, 6, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide32, 6, 2, 1>(GROUP_ARGS) : launch_group<GWide32, 6, 2, 0>(GROUP_ARGS);
     return (int)hipErrorInvalidValue;
 }
 

@@ -31,7 +31,7 @@
 
 namespace mvdetr {
 
-template <typename Cfg, bool FUSED>
+template <typename Cfg, int FUSED>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_tile(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
@@ -50,7 +50,7 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
     return (D == 16 && M % 2 == 0) || D == 32;
 }
 
-template <typename Cfg, bool FUSED>
+template <typename Cfg, int FUSED>
 static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
                        QueryLevels qr, int B, int S, int M, int L, float *out)
@@ -84,7 +84,7 @@ static bool narrow_slices()
 
 #define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out
 
-template <bool FUSED>
+template <int FUSED>
 static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
                          QueryLevels qr, int B, int S, int M, int D, int L, float *out)
@@ -103,15 +103,16 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
     if (msda_group_supported(D, L) && !narrow_slices())
-        return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, B, S, M, D, L, out);
-    return dispatch_tile<false>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out);
+        return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out);
+    return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out);
 }
 
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
-                            int level_major, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
+                            int layout, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
                             int M, int D, int L, float *out)
 {
+    const int level_major = layout & 1, shared_ref = layout & 2;
     const int P = TILE_P;
     const SamplingLayout lay = level_major
         ? SamplingLayout{qstride_l, P * 2, M * P * 2, qstride_w, P, M * P}              // [.., Lq, L, M, P(, 2)]
@@ -122,9 +123,12 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
     if (all_levels && msda_group_supported(D, L) && !narrow_slices())
-        return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay, B, S, M, D, L, out);
-    return dispatch_tile<true>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
-                               QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out);
+        return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
+                                  M, D, L, out);
+    return shared_ref ? dispatch_tile<2>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
+                                         QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out)
+                      : dispatch_tile<1>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
+                                         QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out);
 }
 
 }  // namespace mvdetr

@@ -56,8 +56,10 @@ struct QueryLevels {
 
 // camera-grouped fused forward (msda_forward_group.hip)
 bool msda_group_supported(int D, int L);
+// fused: 0 = final locations / weights (ref unused), 1 = raw + reference points [.., Lq, L, P, 2], 2 = raw + one
+// reference point per (query, level) [.., Lq, L, 2]
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
-                       const float *off, const float *logit, const float *ref, int64_t ref_bstride,
+                       const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out);
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->

@@ -32,7 +32,10 @@ __device__ __forceinline__ void fma4(float2v &lo, float2v &hi, float w, const fl
 // permutation of the Linear's weight rows on the module side, which puts what ONE level iteration of the
 // heads of a tile needs into the same cache lines (the head-major layout spreads a line over 4 level
 // iterations, between which it falls out of L2).
-template <typename Cfg, bool FUSED>
+// FUSED: 0 = final locations / weights; 1 = raw offsets / logits + reference points [.., Lq, L, P, 2];
+// 2 = the same with ONE reference point per (query, level), [.., Lq, L, 2] (MVDeTr's reference map repeats the
+// point P times, mvdetr.py:49-58 with all heights 0): a quarter of the reference bytes and registers.
+template <typename Cfg, int FUSED>
 __device__ __forceinline__ void msda_fwd_tile_body(float *win,
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
@@ -125,7 +128,8 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
         const int64_t bq = active ? (int64_t)b * Lq + q : 0;
         const float *lp = loc + bq * lay.q_l + head * lay.h_l;
         const float *wp = aw + bq * lay.q_w + head * lay.h_w;
-        const float *rp = FUSED ? ref + b * ref_bstride + (active ? q : 0) * L * P * 2 : nullptr;
+        constexpr int RPL = FUSED == 2 ? 2 : P * 2;         // floats of reference points per (query, level)
+        const float *rp = FUSED ? ref + b * ref_bstride + (active ? q : 0) * L * RPL : nullptr;
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;   // this slice of token 0
 
         float2v acc[2 * NV];
@@ -172,9 +176,12 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
             a = *reinterpret_cast<const float4 *>(lp + l * lstep_l);
             b2 = *reinterpret_cast<const float4 *>(lp + l * lstep_l + 4);
             w = *reinterpret_cast<const float4 *>(wp + l * lstep_w);
-            if constexpr (FUSED) {
+            if constexpr (FUSED == 1) {
                 r0 = *reinterpret_cast<const float4 *>(rp + l * P * 2);
                 r1 = *reinterpret_cast<const float4 *>(rp + l * P * 2 + 4);
+            } else if constexpr (FUSED == 2) {
+                const float2 r = *reinterpret_cast<const float2 *>(rp + l * 2);
+                r0 = r1 = make_float4(r.x, r.y, r.x, r.y);
             }
         };
         // FUSED: online softmax over the L*P logits of this (query, head) -- running maximum `smax` and
@@ -312,8 +319,9 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
                 const int pp = bit - l * P;
                 float lx = lp[l * lstep_l + pp * 2 + 0], ly = lp[l * lstep_l + pp * 2 + 1], a = wp[l * lstep_w + pp];
                 if constexpr (FUSED) {
-                    lx = rp[bit * 2 + 0] + lx * (1.f / (float)W);
-                    ly = rp[bit * 2 + 1] + ly * (1.f / (float)H);
+                    const int ri = FUSED == 2 ? l * 2 : bit * 2;
+                    lx = rp[ri + 0] + lx * (1.f / (float)W);
+                    ly = rp[ri + 1] + ly * (1.f / (float)H);
                     a = __expf(a - smax);                  // un-normalised, like the accumulators
                 }
                 const float x = lx * (float)W - 0.5f;

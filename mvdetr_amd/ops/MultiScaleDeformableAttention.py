@@ -102,7 +102,8 @@ def fused_supported(value, num_levels, num_query, num_point, query_levels=None) 
 def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
                                  attn_logits, level_major=False, query_levels=None):
     """Core + the module arithmetic around it (ms_deform_attn.py:100-107) in one kernel (inference):
-    value [B,S,M,D]; reference_points [B or 1, Lq, L, P, 2] (may be a batch-expanded view);
+    value [B,S,M,D]; reference_points [B or 1, Lq, L, P, 2] (may be a batch-expanded view), or [B or 1, Lq, L, 2]
+    when the P sampling points of a (query, level) share one reference point (MVDeTr's map: P identical copies);
     sampling_offsets [B,Lq,M,L,P,2] and attn_logits [B,Lq,M,L,P] are the raw Linear outputs
     ([B,Lq,L,M,P,2] / [B,Lq,L,M,P] with ``level_major``); each may be a column block of a wider GEMM
     output (dense per query, arbitrary query stride).  -> [B, Lq, M*D].
@@ -126,8 +127,10 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
             if not dense_inner or (B > 1 and st[0] != st[1] * Lq):
                 raise RuntimeError(f"{name} tensor has to be contiguous per query")
         qstrides.append(t.stride(1))
-    if reference_points.shape[-4:] != (Lq, L, P, 2) or not reference_points.is_cuda:
-        raise RuntimeError("reference_points must be a CUDA tensor of shape [B or 1, Lq, L, P, 2]")
+    shared_ref = reference_points.dim() == 4
+    if (reference_points.shape[1:] != ((Lq, L, 2) if shared_ref else (Lq, L, P, 2)) or not reference_points.is_cuda
+            or reference_points.dtype != value.dtype or reference_points.shape[0] not in (1, B)):
+        raise RuntimeError("reference_points must be a CUDA tensor of shape [B or 1, Lq, L, P, 2] or [B or 1, Lq, L, 2]")
     if not reference_points[0].is_contiguous():
         reference_points = reference_points.contiguous()
     rstride = reference_points.stride(0) if reference_points.shape[0] > 1 else 0
@@ -138,7 +141,8 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
         rc = _lib.lib().mvdetr_msda_forward_fused_levels_f32(
             _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
             level_start_index.data_ptr(), reference_points.data_ptr(), rstride, sampling_offsets.data_ptr(),
-            attn_logits.data_ptr(), 1 if level_major else 0, qstrides[0], qstrides[1], l0, l1, B, S, M, D, L, Lq,
+            attn_logits.data_ptr(), (1 if level_major else 0) | (2 if shared_ref else 0), qstrides[0], qstrides[1], l0, l1,
+            B, S, M, D, L, Lq,
             P, out.data_ptr())
     _lib.check(rc, "ms_deform_attn_forward_fused")
     return out

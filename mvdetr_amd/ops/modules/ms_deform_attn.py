@@ -43,6 +43,7 @@ class MSDeformAttn(nn.Module):
         self.output_proj = nn.Linear(d_model, d_model)
         self._validated = None
         self._validated_q = None
+        self._shared_ref_cache = None
         # inference calls of deformable-encoder shape run softmax + location arithmetic inside the kernel
         self.fused_inference = True
         self._fused_cache = None
@@ -100,6 +101,19 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         return value
 
+    def _shared_reference(self, reference_points):
+        """[N, Lq, L, P, 2] -> contiguous [1 or N, Lq, L, 2] when the P points of every (query, level) are the same
+        point (MVDeTr's reference map, mvdetr.py:49-58 with all heights 0), else None.  Checked once per tensor
+        (one device sync) and cached: the fused kernel then loads a quarter of the reference bytes."""
+        key = (reference_points.data_ptr(), reference_points._version, tuple(reference_points.shape),
+               reference_points.stride())
+        if self._shared_ref_cache is None or self._shared_ref_cache[0] != key:
+            ref = reference_points[:1] if reference_points.stride(0) == 0 else reference_points
+            first = ref[..., :1, :]
+            same = bool((ref == first).all())
+            self._shared_ref_cache = (key, first.squeeze(-2).contiguous() if same else None)
+        return self._shared_ref_cache[1]
+
     def _check_query_levels(self, spatial_shapes, query_levels, len_q):
         key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(query_levels), len_q)
         if self._validated_q != key:
@@ -140,8 +154,10 @@ class MSDeformAttn(nn.Module):
             raw = F.linear(query, w, b)
             n_off = self.n_heads * self.n_levels * self.n_points * 2
             L, M, P = self.n_levels, self.n_heads, self.n_points
+            shared = self._shared_reference(reference_points)
             out = MSDA.ms_deform_attn_forward_fused(
-                value.contiguous(), input_spatial_shapes, input_level_start_index, reference_points,
+                value.contiguous(), input_spatial_shapes, input_level_start_index,
+                reference_points if shared is None else shared,
                 raw[..., :n_off].unflatten(-1, (L, M, P, 2)), raw[..., n_off:].unflatten(-1, (L, M, P)),
                 level_major=True, query_levels=query_levels)
             return self.output_proj(out)

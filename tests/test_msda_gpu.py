@@ -688,3 +688,62 @@ def test_many_unequal_levels_fall_back_inside_the_group_launch(ops, msda_impl):
     want = torch_oracle.msda_core(value, shapes, loc, aw)
     got, used = _fwd_impl(MSDA, "tile", (value, shapes, lsi, loc, aw))
     assert used == "tile" and (got - want).abs().max().item() < FP32_TOL
+
+
+# ---- one reference point per (query, level), [.., Lq, L, 2] (layout flag bit 1) ------------------------------------
+@pytest.mark.parametrize("lv,D,B", [([(13, 21)] * 7, 16, 1), ([(9, 17)] * 3, 16, 2), ([(8, 12)] * 12, 32, 1),
+                                     ([(12, 20), (6, 10), (12, 20), (3, 5), (8, 8)], 16, 1)])
+@pytest.mark.parametrize("level_major", [False, True])
+def test_fused_shared_reference_point_equals_the_expanded_call(ops, lv, D, B, level_major):
+    from helpers import pyramid_encoder_inputs
+    _, MSDA = ops
+    M, P, L = 8, 4, len(lv)
+    value, shapes, lsi, _, _ = pyramid_encoder_inputs(lv, M=M, D=D, B=B, seed=13)
+    S = value.shape[1]
+    g = torch.Generator().manual_seed(17)
+    off = torch.randn(B, S, M, L, P, 2, generator=g) * 1.5
+    logit = torch.randn(B, S, M, L, P, generator=g)
+    refs = []
+    for H, W in lv:
+        ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+        refs.append(torch.stack([xs / W, ys / H], -1).reshape(-1, 2))
+    ref3 = torch.cat(refs, 0).view(1, S, 1, 2).repeat(1, 1, L, 1) + 0.003 * torch.randn(1, S, L, 2, generator=g)
+    ref5 = ref3.unsqueeze(3).expand(1, S, L, P, 2).contiguous()
+    if level_major:
+        off_k, logit_k = off.permute(0, 1, 3, 2, 4, 5).contiguous(), logit.permute(0, 1, 3, 2, 4).contiguous()
+    else:
+        off_k, logit_k = off, logit
+    args = dev(value, shapes, lsi)
+    full = MSDA.ms_deform_attn_forward_fused(*args, *dev(ref5, off_k, logit_k), level_major=level_major)
+    shared = MSDA.ms_deform_attn_forward_fused(*args, *dev(ref3, off_k, logit_k), level_major=level_major)
+    assert torch.equal(full, shared)                               # same arithmetic, fewer bytes
+    loc = torch_oracle.msda_sampling_locations(ref5.expand(B, -1, -1, -1, -1), off, shapes)
+    aw = torch.softmax(logit.flatten(3), -1).view(B, S, M, L, P)
+    assert (shared.cpu() - torch_oracle.msda_core(value, shapes, loc, aw)).abs().max().item() < FP32_TOL
+    # one rank's query levels take the same reference layout
+    starts = lsi.tolist() + [S]
+    part = MSDA.ms_deform_attn_forward_fused(
+        *args, *dev(ref3[:, starts[1]:starts[2]].contiguous(), off_k[:, starts[1]:starts[2]].contiguous(),
+                    logit_k[:, starts[1]:starts[2]].contiguous()), level_major=level_major, query_levels=(1, 2))
+    assert (part - full[:, starts[1]:starts[2]]).abs().max().item() < 2e-5
+
+
+def test_module_detects_a_shared_reference_point(ops):
+    _, MSDA = ops
+    L, H, W, M, P, d_model = 7, 10, 18, 8, 4, 128
+    mod = _module_with_random_projections(d_model, L, M, P, seed=2).cuda().eval()
+    shapes = torch.tensor([[H, W]] * L).cuda()
+    S = L * H * W
+    query = torch.randn(1, S, d_model, device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)[None].cuda()       # P equal copies
+    with torch.no_grad():
+        a = mod(query, ref, query, shapes, level_start_index(shapes))
+        assert mod._shared_ref_cache[1] is not None and mod._shared_ref_cache[1].shape == (1, S, L, 2)
+        ref2 = ref.clone()
+        ref2[0, 5, 2, 1, 0] += 0.01                                # one point differs: the full tensor is used
+        b = mod(query, ref2, query, shapes, level_start_index(shapes))
+        assert mod._shared_ref_cache[1] is None
+        mod.fused_inference = False
+        c = mod(query, ref, query, shapes, level_start_index(shapes))
+    assert (a - c).abs().max().item() < 2e-5 and (a - b).abs().max().item() > 0
