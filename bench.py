@@ -84,15 +84,21 @@ class KernelTimer:
             e0.record()
             out = fn(*a, **kw)
             e1.record()
-            self.events.append((e0, e1))
+            # algorithmic bytes of THIS launch: value once + locations + weights + output, from the
+            # call's own shapes (a rank of a query-sharded run has fewer queries than value tokens)
+            B, S, M, D = a[0].shape
+            L, Lq = a[1].shape[0], out.shape[1]
+            P = 4
+            self.events.append((e0, e1, 4 * B * (S * M * D + 3 * Lq * M * L * P + Lq * M * D)))
             return out
         return timed
 
     def average_us(self):
+        """(average launch duration in us, launches, average algorithmic bytes per launch)"""
         if not self.events:
-            return None, 0
-        ts = [a.elapsed_time(b) * 1e3 for a, b in self.events]
-        return sum(ts) / len(ts), len(ts)
+            return None, 0, None
+        ts = [a.elapsed_time(b) * 1e3 for a, b, _ in self.events]
+        return sum(ts) / len(ts), len(ts), sum(n for _, _, n in self.events) / len(self.events)
 
 
 def load_traffic():
@@ -219,7 +225,7 @@ def main():
         torch.distributed.barrier()
     elapsed = mdist.barrier_and_max(time.perf_counter() - t0, dev)
     timer.enabled = False
-    k_us, k_n = timer.average_us()
+    k_us, k_n, k_bytes = timer.average_us()
     impl = MSDA.last_forward_impl()
 
     # ---- the hot path alone (warp + shadow transformer), same inputs ------------------------------------
@@ -239,12 +245,10 @@ def main():
 
     if rank != 0:
         return
-    wf = model.world_feat
-    S = int(wf.spatial_shapes.prod(1).sum())
-    L, Mh, D, P = N, 8, wf.hidden_dim // 8, 4
-    alg_bytes = 4 * Bf * (S * Mh * D + 3 * S * Mh * L * P + S * Mh * D)
-    traffic, traffic_src = load_traffic() if (a.config == "wildtrack" and Bf == 1) else (None, None)
-    achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us else None
+    alg_bytes = int(k_bytes) if k_bytes else None          # of the launches actually timed (rank 0's)
+    full_frame = a.config == "wildtrack" and Bf == 1 and not (a.parallel == "views" and world > 1)
+    traffic, traffic_src = load_traffic() if full_frame else (None, None)
+    achieved = alg_bytes / (k_us * 1e-6) / 1e9 if (k_us and alg_bytes) else None
     res = {
         "metric": "multiview frames/s (7-cam Wildtrack) + MSDeformAttn HBM GB/s vs roofline",
         "value": round(frames_per_step * a.steps / elapsed, 3), "unit": "frames/s",

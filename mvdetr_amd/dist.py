@@ -41,7 +41,10 @@ def init_from_env() -> Tuple[int, int, int]:
         use_gpu = torch.cuda.is_available()
         if use_gpu:
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend="nccl" if use_gpu else "gloo", rank=rank, world_size=world)
+        # MVDETR_DIST_BACKEND=gloo: several ranks on ONE GPU for testing (RCCL wants a GPU per rank; gloo stages
+        # CUDA tensors through the host)
+        backend = os.environ.get("MVDETR_DIST_BACKEND") or ("nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 

@@ -1,0 +1,91 @@
+"""Two ranks sharing the one GPU of the test box (gloo backend, CUDA tensors staged through the host): the
+view-sharded frame and the query-sharded shadow transformer run their REAL collectives around the REAL HIP
+kernels and must reproduce the single-process result.  (RCCL itself needs one GPU per rank; the 8-GPU run is
+the driver's.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", MVDETR_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    try:
+        from mvdetr_amd import dist as mdist, geometry
+        from mvdetr_amd.model import build_model
+        from mvdetr_amd.ops import MultiScaleDeformableAttention as MSDA
+        from mvdetr_amd.world_feat import DeformTransWorldFeat
+        r, w, _ = mdist.init_from_env()
+        assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+        msgs = []
+        # 1. whole frames, cameras 2 + 1 over the ranks, both encoder modes
+        model = build_model("mini", seed=0).cuda().eval()
+        with torch.no_grad():
+            for layer in model.world_feat.encoder.layers:
+                layer.self_attn.sampling_offsets.weight.normal_(0, 0.02, generator=torch.Generator(device="cuda").manual_seed(1))
+                layer.self_attn.attention_weights.weight.normal_(0, 0.05, generator=torch.Generator(device="cuda").manual_seed(2))
+        g = torch.Generator().manual_seed(3)
+        imgs = torch.randn(1, 3, 3, *geometry.MINI.input_img_shape, generator=g)
+        M = geometry.random_affine_mats(1, 3, geometry.MINI.input_img_shape, seed=2, translate=0.05, scale=(0.9, 1.1))
+        with torch.no_grad():
+            want = model(imgs.cuda(), M)[0]
+            for encoder in ("sharded", "replicated"):
+                runner = mdist.ViewShardedFrame(model, encoder=encoder)
+                s, e = runner.range
+                got = runner(imgs[:, s:e].cuda(), M)
+                err = max((got[0] - want[0]).abs().max().item(), (got[1] - want[1]).abs().max().item())
+                msgs.append(f"{encoder} {err:.2e}")
+                assert err < 2e-5, msgs
+        # 2. the shadow transformer at 128 channels, 7 cameras 4 + 3: the fused kernel restricted to a rank's levels
+        torch.manual_seed(7)
+        N, H, W, C, B = 7, 24, 72, 128, 1
+        h, wd = H // 2, W // 2
+        ys, xs = torch.meshgrid(torch.arange(h) + 0.5, torch.arange(wd) + 0.5, indexing="ij")
+        ref = torch.stack([xs / wd, ys / h], -1).reshape(1, h * wd, 1, 1, 2).repeat(N, 1, N, 4, 1).view(-1, N, 4, 2)
+        wf = DeformTransWorldFeat(N, (H, W), C, hidden_dim=C, reference_points=ref)
+        with torch.no_grad():
+            for layer in wf.encoder.layers:
+                layer.self_attn.sampling_offsets.weight.normal_(0, 0.02)
+                layer.self_attn.attention_weights.weight.normal_(0, 0.05)
+        wf = wf.cuda().eval()
+        tokens = torch.randn(B, N * h * wd, C, generator=torch.Generator().manual_seed(9)).cuda()
+        with torch.no_grad():
+            want = wf.fuse(tokens, B, h, wd)
+            fusion = mdist.QueryShardedFusion(wf, rank, world)
+            got = fusion(tokens[:, fusion.own_slice(h, wd)].contiguous(), B, h, wd)
+        assert MSDA.last_forward_impl() == "tile_fused"
+        err = (got - want).abs().max().item()
+        assert err < 2e-5, err
+        q.put((rank, True, "; ".join(msgs) + f"; fusion {err:.2e}"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_single_process_frame():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, ok, msg in results:
+        assert ok, f"rank {rank}: {msg}"
