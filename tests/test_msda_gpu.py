@@ -747,3 +747,44 @@ def test_module_detects_a_shared_reference_point(ops):
         mod.fused_inference = False
         c = mod(query, ref, query, shapes, level_start_index(shapes))
     assert (a - c).abs().max().item() < 2e-5 and (a - b).abs().max().item() > 0
+
+
+# ---- seeded sweep over encoder-shaped configurations: every dispatch route against the oracle -------------------
+def _sweep_cases(n=28, seed=2024):
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    for i in range(n):
+        L = rnd.choice([1, 2, 3, 5, 6, 7, 8, 9, 11, 16])
+        D = rnd.choice([16, 16, 32, 8])
+        M = rnd.choice([1, 2, 3, 4, 8]) if D != 8 else 4
+        H, W = rnd.randint(1, 26), rnd.randint(1, 40)
+        B = rnd.choice([1, 1, 2])
+        noise = rnd.choice([0.5, 1.5, 4.0, 9.0])
+        cases.append((i, L, D, M, H, W, B, noise))
+    return cases
+
+
+@pytest.mark.parametrize("i,L,D,M,H,W,B,noise", _sweep_cases())
+def test_encoder_shape_sweep_forward_and_backward(ops, i, L, D, M, H, W, B, noise):
+    _, MSDA = ops
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(L, H, W, M=M, D=D, B=B, seed=100 + i, noise_px=noise)
+    want = torch_oracle.msda_core(value.double(), shapes, loc.double(), aw.double())
+    got = MSDA.ms_deform_attn_forward(*dev(value, shapes, lsi, loc, aw), 64).cpu().double()
+    assert (got - want).abs().max().item() < FP32_TOL
+    go = torch.randn(B, loc.shape[1], M * D, generator=torch.Generator().manual_seed(i))
+    ref = c_oracle.msda_backward(value.double(), shapes, lsi, loc.double(), aw.double(), go.double())
+    grads = [x.cpu().double() for x in MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), 64)]
+    smooth = _away_from_texel_centres(loc, shapes)
+    for a, b, name, scale in zip(grads, ref, ("grad_value", "grad_loc", "grad_aw"), (1.0, float(W), 1.0)):
+        err = (a - b).abs() / (scale + b.abs())
+        if name == "grad_loc":
+            err = err * smooth[..., None]
+        assert err.max().item() < 2e-4, (name, MSDA.last_forward_impl())
+    if MSDA.fused_supported(value.cuda(), L, value.shape[1], 4):
+        ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+        r3 = torch.stack([xs / W, ys / H], -1).reshape(1, H * W, 1, 2).repeat(B, L, L, 1)
+        off = (loc - r3[:, :, None, :, None, :]) * torch.tensor([W, H], dtype=torch.float32)
+        logit = torch.log(aw.clamp_min(1e-30))
+        fused = MSDA.ms_deform_attn_forward_fused(*dev(value, shapes, lsi, r3, off, logit)).cpu().double()
+        assert (fused - want).abs().max().item() < FP32_TOL
