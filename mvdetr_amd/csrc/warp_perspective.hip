@@ -299,7 +299,6 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
     const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
     T *__restrict__ grad_src)
 {
-    constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ WarpTexel<T> tex[WARP_PIX];
     WarpBlock wb;
     if (!warp_block(N, H, W, 1, wb)) return;
@@ -309,25 +308,24 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
         tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W);
     }
     __syncthreads();
-    const int chunks = C / VEC;
     T *view = grad_src + (int64_t)n * h * w * C;
     const int rowC = w * C;
-    for (int item = threadIdx.x; item < WARP_PIX * chunks; item += WARP_CL_THREADS) {
-        const int p = item / chunks, c = (item - p * chunks) * VEC;
+    // One CHANNEL per lane (not a 16-byte chunk as in the forward): the memory-side atomic units take a wave's
+    // atomic instruction as one request per contiguous segment, so 64 consecutive channels of a corner are 4
+    // requests, where 16-byte chunks per lane made every instruction 4-byte pieces 16 bytes apart -- 4x the
+    // requests (measured 1.46 ms -> see DESIGN.md).
+    for (int item = threadIdx.x; item < WARP_PIX * C; item += WARP_CL_THREADS) {
+        const int p = item / C, c = item - p * C;
         const int i = wb.i0 + p / WARP_TW, j = wb.j0 + p % WARP_TW;
         if (i >= H || j >= W) continue;
         const WarpTexel<T> t = tex[p];
         if (!t.valid) continue;
-        const Pack<T, VEC> g = Pack<T, VEC>::load(grad_dst + (((int64_t)n * H + i) * W + j) * C + c);
+        const T g = grad_dst[(((int64_t)n * H + i) * W + j) * C + c];
         T *gp = view + (int64_t)t.o00 * C + c;
-        // the lanes of a pixel cover its whole C-row: each atomic instruction is a run of contiguous segments
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            if (t.valid & 1) atomicAdd(gp + k, t.w00 * g.v[k]);
-            if (t.valid & 2) atomicAdd(gp + C + k, t.w01 * g.v[k]);
-            if (t.valid & 4) atomicAdd(gp + rowC + k, t.w10 * g.v[k]);
-            if (t.valid & 8) atomicAdd(gp + rowC + C + k, t.w11 * g.v[k]);
-        }
+        if (t.valid & 1) atomicAdd(gp, t.w00 * g);
+        if (t.valid & 2) atomicAdd(gp + C, t.w01 * g);
+        if (t.valid & 4) atomicAdd(gp + rowC, t.w10 * g);
+        if (t.valid & 8) atomicAdd(gp + rowC + C, t.w11 * g);
     }
 }
 

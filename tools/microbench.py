@@ -106,6 +106,14 @@ def main():
     report("warp_fwd NHWC", time_us(lambda: warp_perspective(src, Mx, (Hw, Ww), channels_last_out=True), a.iters), wbytes)
     src_cl = src.contiguous(memory_format=torch.channels_last)
     report("warp_fwd NHWC <- NHWC source", time_us(lambda: warp_perspective(src_cl, Mx, (Hw, Ww), channels_last_out=True), a.iters), wbytes)
+    if not a.skip_bwd:
+        from mvdetr_amd.ops.warp import WarpPerspectiveFunction
+        for tag, s_in, nhwc in (("NCHW", src, False), ("NHWC <- NHWC source", src_cl, True)):
+            leaf = s_in.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+            out = warp_perspective(leaf, Mx, (Hw, Ww), channels_last_out=nhwc)
+            go = torch.randn_like(out)
+            fn = lambda: torch.autograd.grad(out, leaf, go, retain_graph=True)  # noqa: E731
+            report(f"warp_bwd {tag} (+memset)", time_us(fn, max(5, a.iters // 3)), wbytes)
     # for scale: a plain device copy of the same number of bytes
     x = torch.empty(wbytes // 8, device="cuda")
     y = torch.empty_like(x)
