@@ -115,15 +115,22 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
     const bool a16 = aligned(value, 16) && aligned(grad_col, 16);
     if constexpr (sizeof(T) == 4) {
         // Encoder-shaped fp32 calls (the shapes the forward tile kernels take): grad_value through fixed-point LDS
-        // windows (msda_backward_tile.hip), the other two gradients from the lane kernel without its atomics.
+        // windows (msda_backward_tile.hip), the other two gradients from LDS-staged value windows (msda_backward_sampling.hip).
         // MVDETR_MSDA_BWD_IMPL=atomic keeps everything on the direct-atomics kernel.
         static const bool tile_ok = [] { const char *e = getenv("MVDETR_MSDA_BWD_IMPL"); return !(e && !strcmp(e, "atomic")); }();
         const bool all16 = a16 && aligned(loc, 16) && aligned(aw, 16) && aligned(grad_value, 16) && aligned(grad_loc, 16) &&
                            aligned(grad_aw, 16);
         if (tile_ok && msda_tile_supported(B, S, M, D, L, Lq, P, all16, 0, L)) {
-            int rc = msda_backward_value_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw);
-            if (rc) return rc;
-            return msda_backward_sampling_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_loc, grad_aw);
+            // a stream-ordered scratch int carries the locality probe's verdict to both kernels: calls whose taps are
+            // far from their queries (e.g. uniformly random locations) run the lane-group backward inside the first
+            // launch instead -- no host synchronisation, no dependence on the caller's allocator
+            int *hits = nullptr;
+            if (hipMallocAsync(reinterpret_cast<void **>(&hits), sizeof(int), st) != hipSuccess) hits = nullptr;
+            int rc = hits ? msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits) : 0;
+            if (!rc) rc = msda_backward_value_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, hits);
+            if (!rc) rc = msda_backward_sampling_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_loc, grad_aw, hits);
+            if (hits) (void)hipFreeAsync(hits, st);
+            return rc;
         }
     }
     // One channel per lane (G = D lanes per head): a wave's atomic instruction then covers whole

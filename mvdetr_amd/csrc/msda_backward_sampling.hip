@@ -55,7 +55,7 @@ template <typename Cfg, int NL>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
-    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw)
+    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw, const int *__restrict__ local_hits)
 {
     extern __shared__ __attribute__((aligned(16))) float vwin[];
     constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, SLICE = Cfg::SLICE, P = TILE_P;
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (!equal) return;          // msda_bwd_value_tile has done all three gradients for such levels
+    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
+    if (!equal) return;          // msda_bwd_value_tile has done all three gradients for such calls
 
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
@@ -196,7 +197,7 @@ using SWide32 = TileCfg<32, 32, 8, 16, 6>;
 template <typename Cfg, int NL>
 static int launch_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                 const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
-                                float *grad_loc, float *grad_aw)
+                                float *grad_loc, float *grad_aw, const int *local_hits)
 {
     static int blocks = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_tile<Cfg, NL>),
@@ -211,15 +212,15 @@ static int launch_sampling_tile(hipStream_t st, const float *go, const float *va
         return (cus * per_cu + 7) / 8 * 8;
     }();
     hipLaunchKernelGGL((msda_bwd_sampling_tile<Cfg, NL>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw);
+                       go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits);
     return (int)hipGetLastError();
 }
 
 int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                 const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
-                                float *grad_loc, float *grad_aw)
+                                float *grad_loc, float *grad_aw, const int *local_hits)
 {
-#define SAMPLING_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw
+#define SAMPLING_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits
     if (D == 16) return L <= 8 ? launch_sampling_tile<SWide16, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide16, 16>(SAMPLING_ARGS);
     if (D == 32) return L <= 8 ? launch_sampling_tile<SWide32, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide32, 16>(SAMPLING_ARGS);
     return (int)hipErrorInvalidValue;

@@ -26,6 +26,7 @@
 // Replaces (with msda_backward.hip) ms_deformable_col2im_cuda's grad_value accumulation
 // (multiview_detector/models/ops/src/cuda/ms_deform_im2col_cuda.cuh:87-152,301-920).
 #include "common.h"
+#include "msda_dispatch.h"
 #include "msda_tile.h"
 #include "msda_backward_lanes.h"
 #include <stdlib.h>
@@ -37,7 +38,8 @@ template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_value_tile(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
-    int L, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw)
+    int L, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw,
+    const int *__restrict__ local_hits)
 {
     extern __shared__ __attribute__((aligned(16))) int win[];        // [SLICE][NTOKP] fixed-point accumulators
     __shared__ float red[Cfg::THREADS / 64];
@@ -51,6 +53,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_value_tile(
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
+    // local_hits: how many of msda_locality_probe's sampled taps stay near their own query cell; too few and
+    // windows are pointless (every tap would take the far path) -- same stand-down as for unequal shapes
+    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;
     if (!equal) {
         // not this kernel's case: the lane-group backward (msda_backward_lanes.h) does all three gradients here,
         // and msda_bwd_sampling_tile, which sees the same shapes, stands down
@@ -263,13 +268,40 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_value_tile(
     }
 }
 
+// Samples MSDA_PROBE_SAMPLES taps spread over the whole call and counts those within MSDA_PROBE_RADIUS pixels of
+// their own query's cell (equal level shapes assumed; with unequal ones the count is ignored anyway).
+__global__ __launch_bounds__(256) void msda_locality_probe(const float *__restrict__ loc, const int64_t *__restrict__ shapes,
+                                                           int B, int S, int M, int L, int *__restrict__ hits)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int H = (int)shapes[0], W = (int)shapes[1];
+    const int64_t taps = (int64_t)B * S * M * L * TILE_P;
+    // a fixed odd stride walks the tap index space evenly
+    const int64_t t = (int64_t)(((unsigned long long)i * 0x9E3779B97F4A7C15ull) % (unsigned long long)taps);
+    const int64_t bq = t / ((int64_t)M * L * TILE_P);
+    const int cell = (int)((bq % S) % ((int64_t)H * W));
+    const float x = loc[2 * t] * (float)W - 0.5f, y = loc[2 * t + 1] * (float)H - 0.5f;
+    const bool hit = i < MSDA_PROBE_SAMPLES && fabsf(x - (float)(cell % W)) <= MSDA_PROBE_RADIUS &&
+                     fabsf(y - (float)(cell / W)) <= MSDA_PROBE_RADIUS;
+    const int n = __syncthreads_count(hit);
+    if (threadIdx.x == 0 && n) atomicAdd(hits, n);
+}
+
+int msda_launch_locality_probe(hipStream_t st, const float *loc, const int64_t *shapes, int B, int S, int M, int L, int *hits)
+{
+    hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(msda_locality_probe, dim3(MSDA_PROBE_SAMPLES / 256), dim3(256), 0, st, loc, shapes, B, S, M, L, hits);
+    return (int)hipGetLastError();
+}
+
 using BWide16 = TileCfg<16, 32, 6, 16, 6, 256>;
 using BWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 
 template <typename Cfg>
 static int launch_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
-                             float *grad_value, float *grad_loc, float *grad_aw)
+                             float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits)
 {
     constexpr int LDS = (Cfg::SLICE + 2) * ((Cfg::WH * Cfg::WW) | 1) * 4;      // accumulators + weight mass
     static int blocks = [] {
@@ -285,16 +317,16 @@ static int launch_value_tile(hipStream_t st, const float *go, const float *value
         return (cus * per_cu + 7) / 8 * 8;
     }();
     hipLaunchKernelGGL((msda_bwd_value_tile<Cfg>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, go, value, shapes,
-                       lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw);
+                       lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits);
     return (int)hipGetLastError();
 }
 
 int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
-                             float *grad_value, float *grad_loc, float *grad_aw)
+                             float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits)
 {
-    if (D == 16) return launch_value_tile<BWide16>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw);
-    if (D == 32) return launch_value_tile<BWide32>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw);
+    if (D == 16) return launch_value_tile<BWide16>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits);
+    if (D == 32) return launch_value_tile<BWide32>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits);
     return (int)hipErrorInvalidValue;
 }
 

@@ -35,12 +35,17 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
 // grad_value of encoder-shaped fp32 calls through fixed-point LDS windows (msda_backward_tile.hip)
 int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
-                             float *grad_value, float *grad_loc, float *grad_aw);
+                             float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits);
+// device-side locality probe shared by the two kernels: *hits = how many of MSDA_PROBE_SAMPLES sampled taps lie
+// within MSDA_PROBE_RADIUS pixels of their own query cell (stream-ordered; `hits` is a device int)
+#define MSDA_PROBE_SAMPLES 16384
+#define MSDA_PROBE_RADIUS 5.5f
+int msda_launch_locality_probe(hipStream_t st, const float *loc, const int64_t *shapes, int B, int S, int M, int L, int *hits);
 
 // grad_sampling_loc / grad_attn_weight of the same calls from LDS-staged value windows (msda_backward_sampling.hip)
 int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                 const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
-                                float *grad_loc, float *grad_aw);
+                                float *grad_loc, float *grad_aw, const int *local_hits);
 
 template <typename T>
 inline MsdaFwdImpl msda_fwd_choose_impl(const T *value, const T *loc, const T *aw, const T *out, int B,
