@@ -14,6 +14,8 @@
 // grad_value is accumulated with hardware fp atomics (global_atomic_add_f32/f64,
 // -munsafe-fp-atomics), i.e. the summation order -- like the reference's atomicAdd
 // (cuh:125-152) -- is not deterministic.
+// Encoder-shaped fp32 calls do not end up here: backward_entry() sends them to msda_backward_tile.hip
+// (grad_value, fixed-point LDS windows) + msda_backward_sampling.hip (the other two gradients).
 #include "common.h"
 #include "msda_dispatch.h"
 #include "msda_backward_lanes.h"
