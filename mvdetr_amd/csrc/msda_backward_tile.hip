@@ -34,21 +34,6 @@
 
 namespace mvdetr {
 
-typedef float f2v __attribute__((ext_vector_type(2)));
-
-// floor(x + 0.5) as an int in ONE instruction (v_cvt_i32_f32 truncates, so round-to-nearest costs v_rndne + v_cvt)
-__device__ __forceinline__ int round_half_up(float x)
-{
-    int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-__device__ __forceinline__ void lds_add(int *p, int v)
-{
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
 template <typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_value_tile(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -205,21 +190,12 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_value_tile(
                                 const float w01 = ay0 * wx1, w00 = ay0 - w01, w11 = ay1 * wx1, w10 = ay1 - w11;
                                 int *w0 = win + lane_off * NTOKP + tok;
 #pragma unroll
-                                for (int k = 0; k < LCH; k += 2) {
-                                    // two channels per v_pk_mul_f32, one v_cvt_rpi_i32_f32 (floor(x + 0.5)) per product:
-                                    // 1.5 VALU instructions per atomic instead of 3 (mul, rndne, cvt)
-                                    const f2v gg = {g[k], g[k + 1]};
-                                    const f2v p00 = gg * (f2v){w00, w00}, p01 = gg * (f2v){w01, w01};
-                                    const f2v p10 = gg * (f2v){w10, w10}, p11 = gg * (f2v){w11, w11};
+                                for (int k = 0; k < LCH; ++k) {
                                     int *wk = w0 + k * NTOKP;
-                                    lds_add(wk, round_half_up(p00.x));
-                                    lds_add(wk + 1, round_half_up(p01.x));
-                                    lds_add(wk + WW, round_half_up(p10.x));
-                                    lds_add(wk + WW + 1, round_half_up(p11.x));
-                                    lds_add(wk + NTOKP, round_half_up(p00.y));
-                                    lds_add(wk + NTOKP + 1, round_half_up(p01.y));
-                                    lds_add(wk + NTOKP + WW, round_half_up(p10.y));
-                                    lds_add(wk + NTOKP + WW + 1, round_half_up(p11.y));
+                                    __hip_atomic_fetch_add(wk, __float2int_rn(w00 * g[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(wk + 1, __float2int_rn(w01 * g[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(wk + WW, __float2int_rn(w10 * g[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_fetch_add(wk + WW + 1, __float2int_rn(w11 * g[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 }
                             }
                         }
