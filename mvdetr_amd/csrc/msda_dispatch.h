@@ -9,12 +9,13 @@ enum class MsdaFwdImpl { Gather, Tile };
 
 // fp32 LDS-tiled encoder kernel (msda_forward_tile.hip).  Only valid when
 // msda_fwd_choose_impl() returned Tile.
+// local_hits: device counter written by msda_launch_locality_probe (or NULL: no probe)
 int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
-                      int P, float *out);
+                      int P, float *out, const int *local_hits);
 inline int msda_forward_tile(hipStream_t, const double *, const int64_t *, const int64_t *,
                              const double *, const double *, int, int, int, int, int, int, int,
-                             double *)
+                             double *, const int *)
 {
     return 1;  // never chosen for fp64
 }

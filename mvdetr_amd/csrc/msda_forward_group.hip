@@ -21,6 +21,7 @@
 #include "msda_dispatch.h"
 #include "msda_tile.h"
 #include "msda_tile_body.h"
+#include "msda_gather_body.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -46,9 +47,17 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
     const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M,
-    float *__restrict__ out)
+    float *__restrict__ out, const int *__restrict__ local_hits)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
+    if constexpr (FUSED == 0) {
+        // the locality probe found the taps far from their queries: windows would be wasted, gather instead
+        if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) {
+            msda_fwd_gather_body<float, 4>((int64_t)blockIdx.x * Cfg::THREADS + threadIdx.x, (int64_t)gridDim.x * Cfg::THREADS,
+                                           value, shapes, lsi, off, logit, B, S, M, Cfg::D, NG, S, TILE_P, out);
+            return;
+        }
+    }
     constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW;
     constexpr int SLICE = Cfg::SLICE, P = TILE_P, NV = Cfg::NV, NSTAGE = Cfg::NSTAGE, LCH = SLICE / 2, L = NG;
     constexpr int RPP = Cfg::ROWS_PER_PASS;
@@ -304,7 +313,7 @@ using GQuad32 = TileCfg<32, 32, 6, 16, 6, 768>;
 template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
-                        SamplingLayout lay, int B, int S, int M, float *out)
+                        SamplingLayout lay, int B, int S, int M, float *out, const int *local_hits)
 {
     // dynamic LDS: the larger of this kernel's window and the fallback body's
     constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
@@ -322,7 +331,7 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits);
     return (int)hipGetLastError();
 }
 
@@ -334,9 +343,9 @@ bool msda_group_supported(int D, int L)
 
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
-                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out)
+                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits)
 {
-#define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out
+#define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits
     if (L >= 9 && L <= 16) {           // many cameras: 4 lane groups x up to 4 cameras (NG is the template's loop bound)
         switch ((D == 32 ? 100 : 0) + L) {
 #define QUAD_CASE(DD, LL, CFG)                                                                                       \

@@ -26,6 +26,7 @@
 #include "msda_dispatch.h"
 #include "msda_tile.h"
 #include "msda_tile_body.h"
+#include "msda_gather_body.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,9 +37,17 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw,
     const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, QueryLevels qr, int B, int S, int M,
-    int L, float *__restrict__ out)
+    int L, float *__restrict__ out, const int *__restrict__ local_hits)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
+    if constexpr (FUSED == 0) {
+        // the locality probe found the taps far from their queries: windows would be wasted, gather instead
+        if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) {
+            msda_fwd_gather_body<float, 4>((int64_t)blockIdx.x * Cfg::THREADS + threadIdx.x, (int64_t)gridDim.x * Cfg::THREADS,
+                                           value, shapes, lsi, loc, aw, B, S, M, Cfg::D, L, S, TILE_P, out);
+            return;
+        }
+    }
     msda_fwd_tile_body<Cfg, FUSED>(win, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out);
 }
 
@@ -53,7 +62,7 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
 template <typename Cfg, int FUSED>
 static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
-                       QueryLevels qr, int B, int S, int M, int L, float *out)
+                       QueryLevels qr, int B, int S, int M, int L, float *out, const int *local_hits)
 {
     static int blocks = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>),
@@ -69,7 +78,7 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
     }();
     hipLaunchKernelGGL((msda_fwd_tile<Cfg, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
-                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out);
+                       st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out, local_hits);
     return (int)hipGetLastError();
 }
 
@@ -82,12 +91,12 @@ static bool narrow_slices()
     return v;
 }
 
-#define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out
+#define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out, local_hits
 
 template <int FUSED>
 static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                          const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
-                         QueryLevels qr, int B, int S, int M, int D, int L, float *out)
+                         QueryLevels qr, int B, int S, int M, int D, int L, float *out, const int *local_hits = nullptr)
 {
     const bool narrow = narrow_slices();
     if (D == 16) return narrow ? launch_tile<CfgNarrow16, FUSED>(TILE_ARGS) : launch_tile<CfgWide16, FUSED>(TILE_ARGS);
@@ -97,14 +106,14 @@ static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shap
 
 int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
-                      int P, float *out)
+                      int P, float *out, const int *local_hits)
 {
     const SamplingLayout lay = {M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P};     // [.., Lq, M, L, P(, 2)]
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
     if (msda_group_supported(D, L) && !narrow_slices())
-        return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out);
-    return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out);
+        return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
+    return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out, local_hits);
 }
 
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,

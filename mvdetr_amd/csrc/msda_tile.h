@@ -60,7 +60,8 @@ bool msda_group_supported(int D, int L);
 // reference point per (query, level) [.., Lq, L, 2]
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
-                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out);
+                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out,
+                       const int *local_hits = nullptr);
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
 // scalar registers).

@@ -72,6 +72,8 @@ def main():
             if used == impl:
                 report(f"msda_fwd[{tag}] impl={used}", time_us(fn, a.iters), fwd_bytes)
         MSDA.set_forward_impl("auto")
+        fn = lambda: MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, aw, 64)  # noqa: E731
+        report(f"msda_fwd[{tag}] auto (+probe)", time_us(fn, a.iters), fwd_bytes)
         if not a.skip_bwd:
             go = torch.randn(B, S, M * D, device="cuda")
             fn = lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, go, 64)  # noqa: E731
