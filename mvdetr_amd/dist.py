@@ -60,9 +60,11 @@ def partition_views(num_views: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=None, hw: int = None) -> torch.Tensor:
+def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=None, hw: int = None,
+                           async_op: bool = False):
     """local_tokens [B, n_local*hw, C] (this rank's views, possibly none) -> [B, num_views*hw, C] on
-    every rank, views in camera order.  One all_gather_into_tensor; ragged shards are padded to the
+    every rank, views in camera order (``async_op``: a zero-argument callable returning that tensor once the
+    collective is done, with a ``length`` attribute = num_views*hw).  One all_gather_into_tensor; ragged shards are padded to the
     largest shard and the padding is dropped after the collective.  Inference only: the collective is
     not differentiable (the tokens are detached)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -87,10 +89,21 @@ def all_gather_view_tokens(local_tokens: torch.Tensor, num_views: int, group=Non
             send[:, :n_loc * hw] = local_tokens.detach()
         # concatenated-along-dim-0 form: accepted by both RCCL and gloo
         recv = local_tokens.new_empty(world * B, n_max * hw, C)
-        dist.all_gather_into_tensor(recv, send.contiguous(), group=group)
-    recv = recv.view(world, B, n_max * hw, C)
-    pieces = [recv[r, :, :(e - s) * hw] for r, (s, e) in enumerate(parts) if e > s]
-    return torch.cat(pieces, dim=1)
+        work = dist.all_gather_into_tensor(recv, send.contiguous(), group=group, async_op=async_op)
+
+    def assemble():
+        if work is not None:
+            work.wait()                    # the current stream waits for the collective; the host does not block
+        r4 = recv.view(world, B, n_max * hw, C)
+        pieces = [r4[r, :, :(e - s) * hw] for r, (s, e) in enumerate(parts) if e > s]
+        return torch.cat(pieces, dim=1)
+
+    if not async_op:
+        return assemble()
+    # the caller resolves it when it needs the tokens (MSDeformAttn does so after enqueueing its own GEMM, so the
+    # collective -- on RCCL's stream -- overlaps that GEMM)
+    assemble.length = num_views * hw
+    return assemble
 
 
 class QueryShardedFusion:
@@ -116,6 +129,8 @@ class QueryShardedFusion:
         """Encoder layer i on this rank's queries, given the projected values of ALL cameras."""
         s, e = self.views
         if e == s:
+            if callable(value_all):
+                value_all()                # an idle rank still completes the collective it took part in
             return src_own
         wf, own = self.wf, self.own_slice(h, w)
         B = src_own.shape[0]
@@ -143,7 +158,8 @@ class QueryShardedFusion:
         the summation order of the all-reduce)."""
         src = local_tokens
         for i in range(self.wf.encoder.num_layers):
-            value = all_gather_view_tokens(self.layer_value(i, src), self.wf.num_cam, self.group, hw=h * w)
+            value = all_gather_view_tokens(self.layer_value(i, src), self.wf.num_cam, self.group, hw=h * w,
+                                           async_op=True)          # resolved inside the attention module
             src = self.layer_update(i, src, value, h, w)
         part = self.merge_partial(src, B, h, w).contiguous()
         if self.world > 1:

@@ -94,7 +94,12 @@ def fused_supported(value, num_levels, num_query, num_point, query_levels=None) 
     """True when ms_deform_attn_forward_fused takes this call (deformable-encoder shapes, fp32)."""
     if not value.is_cuda or value.dtype != torch.float32:
         return False
-    B, S, M, D = value.shape
+    return fused_supported_dims(*value.shape, num_levels, num_query, num_point, query_levels)
+
+
+def fused_supported_dims(B, S, M, D, num_levels, num_query, num_point, query_levels=None) -> bool:
+    """The same from the dimensions alone (CUDA fp32 tensors assumed): for callers whose value tensor is still in
+    flight (a pending all-gather, mvdetr_amd/dist.py)."""
     l0, l1 = (0, num_levels) if query_levels is None else query_levels
     return bool(_lib.lib().mvdetr_msda_fused_levels_supported(B, S, M, D, num_levels, num_query, num_point, l0, l1))
 

@@ -134,24 +134,33 @@ class MSDeformAttn(nn.Module):
         ``query_levels=(l0, l1)`` promises that the Lq queries are exactly the tokens of levels l0..l1-1, which
         lets the fused kernel take the call (it is only a hint: results do not depend on it)."""
         N, Len_q, _ = query.shape
-        if projected_value is not None:
-            value = projected_value
-            Len_in = value.shape[1]
-            self._check_lengths(input_spatial_shapes, Len_in)
+        M, D = self.n_heads, self.d_model // self.n_heads
+        # ``projected_value`` may also be a zero-argument callable returning the tensor, with a ``length`` attribute
+        # (= sum H_l*W_l): a value that is still in flight (an asynchronous all-gather).  It is resolved as late as
+        # possible -- after the offsets/logits GEMM has been enqueued -- so that the collective overlaps that GEMM.
+        pending = projected_value if callable(projected_value) else None
+        if pending is not None:
+            value, Len_in = None, int(pending.length)
+        elif projected_value is not None:
+            value, Len_in = projected_value, projected_value.shape[1]
         else:
             Len_in = input_flatten.shape[1]
-            self._check_lengths(input_spatial_shapes, Len_in)
             value = self.project_value(input_flatten, input_padding_mask)
-        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        self._check_lengths(input_spatial_shapes, Len_in)
         if query_levels is not None:
             self._check_query_levels(input_spatial_shapes, query_levels, Len_q)
+        needs_grad = torch.is_grad_enabled() and ((value is not None and value.requires_grad) or query.requires_grad
+                                                  or self.sampling_offsets.weight.requires_grad)
         if (self.fused_inference and reference_points.shape[-1] == 2 and reference_points.dim() == 5
-                and not (torch.is_grad_enabled() and (value.requires_grad or query.requires_grad
-                                                      or self.sampling_offsets.weight.requires_grad))
-                and MSDA.fused_supported(value, self.n_levels, Len_q, self.n_points, query_levels)):
+                and not needs_grad and query.is_cuda and query.dtype == torch.float32
+                and (value is None or (value.is_cuda and value.dtype == torch.float32))
+                and MSDA.fused_supported_dims(N, Len_in, M, D, self.n_levels, Len_q, self.n_points, query_levels)):
             # one GEMM for offsets + logits, rows permuted to level-major (see _fused_projection)
             w, b = self._fused_projection()
             raw = F.linear(query, w, b)
+            if pending is not None:
+                value = pending()
+            value = value.view(N, Len_in, M, D)
             n_off = self.n_heads * self.n_levels * self.n_points * 2
             L, M, P = self.n_levels, self.n_heads, self.n_points
             shared = self._shared_reference(reference_points)
@@ -161,6 +170,9 @@ class MSDeformAttn(nn.Module):
                 raw[..., :n_off].unflatten(-1, (L, M, P, 2)), raw[..., n_off:].unflatten(-1, (L, M, P)),
                 level_major=True, query_levels=query_levels)
             return self.output_proj(out)
+        if pending is not None:
+            value = pending()
+        value = value.view(N, Len_in, M, D)
         offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
         weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
