@@ -64,11 +64,7 @@ constexpr int NSTAGE = (COPY_ITEMS + THREADS - 1) / THREADS;   // 6
 #ifndef MVDETR_QUAD_TAP
 #define MVDETR_QUAD_TAP 1
 #endif
-#ifndef MVDETR_QUAD_SINGLE
-#define MVDETR_QUAD_SINGLE 0
-#endif
-constexpr bool SINGLE = MVDETR_QUAD_SINGLE;              // 1: one window buffer, synchronous copy, two workgroups per CU
-constexpr int LDS_BYTES = (SINGLE ? 1 : 2) * WIN_FLOATS * 4;
+constexpr int LDS_BYTES = 2 * WIN_FLOATS * 4;             // double-buffered window
 static_assert(WW % 2 == 0, "token parity == column parity needs an even window width");
 static_assert((WIN_FLOATS * 4) % 256 == 0, "both buffers start on a bank row");
 
@@ -94,6 +90,43 @@ __device__ __forceinline__ float4 buf_f4(rsrc_t r, unsigned voff, unsigned soff)
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
 constexpr unsigned OOB = 0x80000000u;                     // a byte offset no supported tensor reaches
+
+// The loads of the main loop are issued from inline asm and waited for with hand-counted s_waitcnt vmcnt(N).  hipcc's
+// own placement does not survive the loop's back edge: for data requested one level ahead it emitted vmcnt(0..9)
+// where 24 loads may stay in flight, which parked every wave behind the loads it had just issued (measured: a
+// (camera, level) step took 1.4 us with, 0.4 us without sampling loads in flight).  Rules that make this safe:
+//   * every VMEM instruction of the steady-state loop is one of these (no compiler loads, no spills inside it), so
+//     the number of younger loads at each wait is known; extra VMEM work elsewhere (the job epilogue's loads and
+//     stores) is younger than anything waited for and only makes a wait stricter;
+//   * a destination register is not touched between its load and the wait statement that names it ("+v")
+//     (tools/check_quad_asm.py audits the generated code for that).
+typedef int desc4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ desc4 make_desc(const void *base, unsigned bytes)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    desc4 d = {__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu)),
+               __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+    return d;
+}
+__device__ __forceinline__ float asm_load1(desc4 d, unsigned voff, unsigned soff)
+{
+    float r;
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(d), "s"(soff) : "memory");
+    return r;
+}
+__device__ __forceinline__ float2 asm_load2(desc4 d, unsigned voff, unsigned soff)
+{
+    float2 r;
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(d), "s"(soff) : "memory");
+    return r;
+}
+// 16 bytes per lane straight into LDS (no VGPRs): lane i's chunk lands at lds_addr + 16 * i; out-of-range reads store 0
+__device__ __forceinline__ void asm_dma16(desc4 d, unsigned voff, unsigned soff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(d), "s"(soff), "s"(lds_addr) : "memory");
+}
 
 template <int P> __device__ __forceinline__ int qb_i(int v)
 {
@@ -231,7 +264,7 @@ __device__ void msda_fwd_quad_generic(const float *__restrict__ value, const int
 // FUSED: 0 = `off` / `logit` hold final sampling locations / attention weights (public contract), `ref` unused;
 // 1 = raw offsets / logits + reference points [.., Lq, L, P, 2]; 2 = raw + one point per (query, level) [.., Lq, L, 2].
 template <int D, int NG, int FUSED>
-__global__ __launch_bounds__(quad::THREADS, quad::SINGLE ? 6 : 3) void msda_fwd_quad(
+__global__ __launch_bounds__(quad::THREADS, 3) void msda_fwd_quad(
     const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const float *__restrict__ off, const float *__restrict__ logit, const float *__restrict__ ref,
     int64_t ref_bstride, SamplingLayout lay, int B, int S, int M, float *__restrict__ out,
@@ -277,65 +310,102 @@ __global__ __launch_bounds__(quad::THREADS, quad::SINGLE ? 6 : 3) void msda_fwd_
     // t -> job: XCD k (workgroups t = k mod 8) takes a contiguous band of jobs
     auto job_of = [&](int t) { return (t >> 3) < jobs8 ? (t & 7) * jobs8 + (t >> 3) : jobs; };
 
-    float4 stage[NSTAGE];
+    // ---- what a lane needs to know about a job ----------------------------------------------------------------------
+    struct JobCtx {
+        int hs, b, oy, ox, cell;
+        bool active;
+        unsigned lane_l, lane_w, lane_r;                   // byte offsets of this lane's sampling point inside a query row
+    };
+    constexpr int RPL = FUSED == 2 ? 2 : P * 2;
+    auto make_ctx = [&](int job) {
+        JobCtx k;
+        const int u2 = job / HS, tin = u2 % per_level;
+        k.hs = job % HS;
+        k.b = u2 / per_level;
+        k.oy = (tin / tcols) * TH - R;
+        k.ox = (tin % tcols) * TW - R;
+        const int qy = k.oy + R + qly, qx = k.ox + R + qlx;
+        k.active = qy < Hq && qx < Wq;
+        k.cell = k.active ? qy * Wq + qx : 0;
+        const int head = (k.hs * SLICE + sub * 16) / D;
+        k.lane_l = (unsigned)(k.cell * lay.q_l + head * lay.h_l + j * 2) * 4u;
+        k.lane_w = (unsigned)(k.cell * lay.q_w + head * lay.h_w + j) * 4u;
+        k.lane_r = (unsigned)(k.cell * L * RPL + (FUSED == 2 ? 0 : j * 2)) * 4u;
+        return k;
+    };
+
+    // ---- window staging: LDS-DMA, NSTAGE 16-byte chunks per lane and level, no registers ----------------------------
+    // chunk i of the window (i = tid + k * THREADS) goes to byte 16 * i of the buffer: a wave's 64 chunks are contiguous
     unsigned stage_off[NSTAGE];                            // byte offset of this lane's k-th window chunk from the level base
-    // where the window of the tile of `job` sits (per job; the level only moves the scalar offset)
-    auto plan = [&](int job) {
-        const int tin = (job / HS) % per_level;
-        const int oy = (tin / tcols) * TH - R, ox = (tin % tcols) * TW - R;
+    const unsigned lds_win = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)win;
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
+    // where the window of a job's tile sits (per job; the level only moves the scalar offset)
+    auto plan = [&](const JobCtx &k) {
 #pragma unroll
-        for (int k = 0; k < NSTAGE; ++k) {
-            const int i = tid + k * THREADS;
+        for (int i0 = 0; i0 < NSTAGE; ++i0) {
+            // the last pass covers only 192 chunks (3 waves); the other waves repeat their previous chunk so that
+            // every wave issues the same number of loads per level
+            const int kk = (tid + i0 * THREADS < COPY_ITEMS) ? i0 : i0 - 1;
+            const int i = tid + kk * THREADS;
             const int tok = i >> 3, ch = i & 7;
             const int wy = tok / WW, wx = tok - wy * WW;
-            const int gy = oy + wy, gx = ox + wx;
-            const bool ok = i < COPY_ITEMS && (unsigned)gy < (unsigned)Hq && (unsigned)gx < (unsigned)Wq;
-            stage_off[k] = ok ? (unsigned)((gy * Wq + gx) * row + ch * 4) * 4u : OOB;       // outside the level: zeros
+            const int gy = k.oy + wy, gx = k.ox + wx;
+            const bool ok = (unsigned)gy < (unsigned)Hq && (unsigned)gx < (unsigned)Wq;
+            stage_off[i0] = ok ? (unsigned)((gy * Wq + gx) * row + ch * 4) * 4u : OOB;     // outside the level: zeros
         }
     };
-    // window of level l of the planned job -> stage registers
-    auto issue = [&](int job, int l) {
-        const int hs = job % HS, b = job / HS / per_level;
-        const rsrc_t rv = make_rsrc(value + (int64_t)b * S * row, (unsigned)S * row * 4u);
-        const unsigned so = (unsigned)(lvl0[l] * row + hs * SLICE) * 4u;
+    auto issue = [&](const JobCtx &k, int l, int buf) {
+        const desc4 dv = make_desc(value + (int64_t)k.b * S * row, (unsigned)S * row * 4u);
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((lvl0[l] * row + k.hs * SLICE) * 4);
 #pragma unroll
-        for (int k = 0; k < NSTAGE; ++k) stage[k] = buf_f4(rv, stage_off[k], so);
+        for (int i0 = 0; i0 < NSTAGE; ++i0) {
+            const unsigned kk = (wave_u * 64 + i0 * THREADS < COPY_ITEMS) ? i0 : i0 - 1;       // (wave-uniform)
+            asm_dma16(dv, stage_off[i0], so, lds_win + (unsigned)buf * (WIN_FLOATS * 4) + (kk * THREADS + wave_u * 64) * 16u);
+        }
     };
-    auto commit = [&](float *buf) {
-#pragma unroll
-        for (int k = 0; k < NSTAGE; ++k) {
-            const int i = tid + k * THREADS;
-            if (i < COPY_ITEMS) *reinterpret_cast<float4 *>(buf + i * 4) = stage[k];
+
+    // ---- sampling data of this lane's point, one register set per camera, refilled ONE LEVEL ahead -----------------
+    // (A (camera, level) step issues in a few hundred cycles but a load takes a few thousand under load.)
+    constexpr int LP = FUSED ? 3 : 2;                      // loads per (camera, level) step
+    constexpr int AHEAD = (NG - 1) * LP + NSTAGE;          // loads younger than a step's data when it is consumed
+    static_assert(AHEAD < 64 && NG * LP < 64, "vmcnt is a 6-bit counter");
+    float2 n_o[NG], n_r[NG];
+    float n_w[NG];
+    auto load_cam = [&](int c, const JobCtx &k, int l) {
+        const int64_t bS = (int64_t)k.b * S;
+        const desc4 d_off = make_desc(off + bS * lay.q_l, (unsigned)S * lay.q_l * 4u);
+        const desc4 d_log = make_desc(logit + bS * lay.q_w, (unsigned)S * lay.q_w * 4u);
+        n_o[c] = asm_load2(d_off, k.lane_l, (unsigned)__builtin_amdgcn_readfirstlane((lvl0[c] * lay.q_l + l * lay.l_l) * 4));
+        n_w[c] = asm_load1(d_log, k.lane_w, (unsigned)__builtin_amdgcn_readfirstlane((lvl0[c] * lay.q_w + l * lay.l_w) * 4));
+        n_r[c] = make_float2(0, 0);
+        if constexpr (FUSED != 0) {
+            const desc4 d_ref = make_desc(ref + k.b * ref_bstride, (unsigned)S * L * RPL * 4u);
+            n_r[c] = asm_load2(d_ref, k.lane_r, (unsigned)__builtin_amdgcn_readfirstlane((lvl0[c] * L * RPL + l * RPL) * 4));
         }
     };
 
     int t = blockIdx.x;
     int job = job_of(t);
     if (job >= jobs) return;                               // (uniform) nothing for this workgroup
-    plan(job);
-    issue(job, 0);
-    commit(win);
+    JobCtx cur = make_ctx(job);
+    plan(cur);
+    // prologue: the same load order as one level of the steady state (window, then camera by camera)
+    issue(cur, 0, 0);
+#pragma unroll
+    for (int c = 0; c < NG; ++c) load_cam(c, cur, 0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG * LP) : "memory");           // the window has landed
     __syncthreads();
     int pb = 0;
 
     for (;;) {
-        const int hs = job % HS, u2 = job / HS;
-        const int tin = u2 % per_level, b = u2 / per_level;
-        const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
-        const int oy = Y0 - R, ox = X0 - R;
+        const int hs = cur.hs, oy = cur.oy, ox = cur.ox, cell = cur.cell;
+        const bool active = cur.active;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
-        const int qy = Y0 + qly, qx = X0 + qlx;
-        const bool active = qy < Hq && qx < Wq;
-        const int cell = active ? qy * Wq + qx : 0;
-        const int head = (hs * SLICE + sub * 16) / D;
-        const int64_t bS = (int64_t)b * S;
-        // per-lane parts of the sampling-data addresses (bytes from a wave-uniform base): own point j of (cell, head)
-        const unsigned lane_l = (unsigned)(cell * lay.q_l + head * lay.h_l + j * 2) * 4u;
-        const unsigned lane_w = (unsigned)(cell * lay.q_w + head * lay.h_w + j) * 4u;
-        constexpr int RPL = FUSED == 2 ? 2 : P * 2;
-        const unsigned lane_r = (unsigned)(cell * L * RPL + (FUSED == 2 ? 0 : j * 2)) * 4u;
-        const float *refb = FUSED ? ref + b * ref_bstride : nullptr;
+        const int64_t bS = (int64_t)cur.b * S;
+        const unsigned lane_l = cur.lane_l, lane_w = cur.lane_w, lane_r = cur.lane_r;
+        const float *refb = FUSED ? ref + cur.b * ref_bstride : nullptr;
         const int next_job = job_of(t + (int)gridDim.x);
+        const JobCtx nxt = make_ctx(next_job < jobs ? next_job : job);     // (the last job prefetches itself: harmless)
 
         float4 acc[NG];
         float smax[NG], ssum[NG];
@@ -349,51 +419,29 @@ __global__ __launch_bounds__(quad::THREADS, quad::SINGLE ? 6 : 3) void msda_fwd_
 #pragma unroll
         for (int c = 0; c < (NG + 1) / 2; ++c) miss[c] = 0;
 
-        float2 n_o[NG], n_r[NG];
-        float n_w[NG];
-        const rsrc_t r_off = make_rsrc(off + bS * lay.q_l, (unsigned)S * lay.q_l * 4u);
-        const rsrc_t r_log = make_rsrc(logit + bS * lay.q_w, (unsigned)S * lay.q_w * 4u);
-        const rsrc_t r_ref = make_rsrc(FUSED ? ref + b * ref_bstride : value, (unsigned)S * L * RPL * 4u);
-        // sampling data of this lane's point for (camera c, level l)
-        auto load_cam = [&](int c, int l) {
-            {
-#ifdef MVDETR_QUAD_NOSAMP
-                n_o[c] = make_float2(0.37f * (j + 1) + c, -0.61f * (j + 1) + l);
-                n_w[c] = 0.1f * j + 0.01f * c;
-                n_r[c] = make_float2((qx + 0.5f) * iw, (qy + 0.5f) * ih);
-#else
-                n_o[c] = buf_f2(r_off, lane_l, (unsigned)(lvl0[c] * lay.q_l + l * lay.l_l) * 4u);
-                n_w[c] = buf_f1(r_log, lane_w, (unsigned)(lvl0[c] * lay.q_w + l * lay.l_w) * 4u);
-                n_r[c] = make_float2(0, 0);
-                if constexpr (FUSED != 0) n_r[c] = buf_f2(r_ref, lane_r, (unsigned)(lvl0[c] * L * RPL + l * RPL) * 4u);
-#endif
-            }
-        };
         for (int l = 0; l < L; ++l) {
-            const bool more = l + 1 < L || next_job < jobs;
             const int tr = ((t / (int)gridDim.x) * L + l) * 8;
             QTRACE(tr + 0);
-            if constexpr (!SINGLE) {
-                if (l + 1 == L && more) plan(next_job);
-                if (more) issue(l + 1 < L ? job : next_job, l + 1 < L ? l + 1 : 0);
+            // the step after this one: next level of this job, or level 0 of the next job
+            const bool last = l + 1 == L;
+            JobCtx pf = cur;
+            if (last) {
+                pf = nxt;
+                plan(nxt);
             }
+            const int pl = last ? 0 : l + 1;
+            issue(pf, pl, pb ^ 1);
             const char *lane_base = reinterpret_cast<const char *>(win + pb * WIN_FLOATS) + lane_byte;
-
-            // Sampling data is requested ONE LEVEL ahead: camera c's registers are refilled with level l+1's data as soon as
-            // level l's have been consumed.  (A (camera, level) step issues in ~500 cycles but a load takes a few thousand
-            // under load; with a one-step-ahead prefetch every wave sat parked in s_waitcnt.)
-            if (l == 0) {
-#pragma unroll
-                for (int c = 0; c < NG; ++c) load_cam(c, 0);
-            }
             QTRACE(tr + 1);
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
                 if (c == 1) QTRACE(tr + 2);
                 if (c == 4) QTRACE(tr + 3);
+                // this step's sampling data was requested one level ago; AHEAD younger loads may stay in flight
+                asm volatile("s_waitcnt vmcnt(%3)" : "+v"(n_o[c]), "+v"(n_w[c]), "+v"(n_r[c]) : "n"(AHEAD) : "memory");
                 const float2 o = n_o[c], r = n_r[c];
                 const float lg = n_w[c];
-                if (l + 1 < L) load_cam(c, l + 1);
+                load_cam(c, pf, pl);
                 float x, y, a;
                 if constexpr (FUSED != 0) {
                     const float m = fmaxf(smax[c], quad_max(lg));
@@ -434,22 +482,12 @@ __global__ __launch_bounds__(quad::THREADS, quad::SINGLE ? 6 : 3) void msda_fwd_
                 asm volatile("" : "+v"(acc[c].x), "+v"(acc[c].y), "+v"(acc[c].z), "+v"(acc[c].w));   // this camera's FMAs stay here
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (SINGLE) {
-                __syncthreads();
-                if (more) {
-                    if (l + 1 == L) plan(next_job);
-                    issue(l + 1 < L ? job : next_job, l + 1 < L ? l + 1 : 0);
-                    commit(win);
-                }
-                __syncthreads();
-            } else {
-                QTRACE(tr + 4);
-                if (more) commit(win + (pb ^ 1) * WIN_FLOATS);
-                QTRACE(tr + 5);
-                __syncthreads();
-                QTRACE(tr + 6);
-                pb ^= 1;
-            }
+            QTRACE(tr + 4);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG * LP) : "memory");       // the next window has landed
+            QTRACE(tr + 5);
+            __syncthreads();
+            QTRACE(tr + 6);
+            pb ^= 1;
         }
 
         // ---- taps that left their window: straight from global memory (rare) ----------------------------------
@@ -509,6 +547,7 @@ __global__ __launch_bounds__(quad::THREADS, quad::SINGLE ? 6 : 3) void msda_fwd_
 
         if (next_job >= jobs) break;
         job = next_job;
+        cur = nxt;
         t += (int)gridDim.x;
     }
 }
@@ -526,7 +565,7 @@ static int launch_quad(hipStream_t st, const float *value, const int64_t *shapes
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        return ((quad::SINGLE ? 2 : 1) * cus + 7) / 8 * 8;  // one workgroup per CU (2 x 64.5 KB of LDS each)
+        return (cus + 7) / 8 * 8;                          // one workgroup per CU (2 x 64.5 KB of LDS each)
     }();
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(quad::THREADS), quad::LDS_BYTES, st, value, shapes, lsi, off,
                        logit, ref, ref_bstride, lay, B, S, M, out, local_hits);
