@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 6
+#define MVDETR_OPS_ABI_VERSION 7
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -63,7 +63,15 @@ int mvdetr_msda_forward_f64(void *stream, const double *value, const int64_t *sp
  *                    level iteration reads in the same cache lines.  Bit 1 (2): reference_points is
  *                    [*, num_query, num_levels, 2], ONE point per (query, level) shared by the num_point sampling
  *                    points -- what MVDeTr's reference map holds P copies of (mvdetr.py:49-58 with all heights 0);
- *                    a quarter of the reference bytes.  Other bits: hipErrorInvalidValue.
+ *                    a quarter of the reference bytes.  Bit 2 (4), not together with bit 0: ONE raw tensor
+ *                    [batch, num_query, num_heads / g, num_levels, (g x num_point x 2 offsets | g x num_point logits)]
+ *                    with g = 32 / channels heads per 128-byte slice of the token row, again a permutation of the
+ *                    Linears' weight rows: everything one workgroup reads for a (query, level) is one contiguous run
+ *                    of 12 g floats (the kernel is bound by the number of cache lines a CU can miss on, and the plain
+ *                    layouts fetch a 128-byte line for 32 or 64 of its bytes); `sampling_offsets` points at the tensor,
+ *                    `attn_logits` must equal sampling_offsets + 8 g and the two query strides must be equal.
+ *                    Bit 3 (8), only with bit 1: reference_points is [*, num_levels, num_query, 2] (neighbouring
+ *                    queries of a level in the same cache lines).  Other bits: hipErrorInvalidValue.
  *   offsets_query_stride / logits_query_stride: floats from one query's block to the next (0 = dense), so
  *                    both may be column blocks of one wider GEMM output; multiples of 4
  * Only the shapes the LDS-tiled kernel takes are supported (fp32, channels 16 or 32, num_point 4,

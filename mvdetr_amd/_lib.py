@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]

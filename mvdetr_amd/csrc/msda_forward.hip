@@ -195,7 +195,18 @@ int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const
         return (int)hipErrorInvalidValue;
     if (query_level_begin < 0 || query_level_end <= query_level_begin || query_level_end > num_levels)
         return (int)hipErrorInvalidValue;
-    if (level_major & ~3) return (int)hipErrorInvalidValue;             // bit 0 level-major raw tensors, bit 1 shared reference point
+    // bit 0 level-major raw tensors, bit 1 one reference point per (query, level), bit 2 slice-interleaved raw tensor
+    // (offsets and logits in one run per (query, slice, level); excludes bit 0), bit 3 level-major reference points
+    // [.., L, Lq, 2] (needs bit 1)
+    if ((level_major & ~15) || ((level_major & 4) && (level_major & 1)) || ((level_major & 8) && !(level_major & 2)))
+        return (int)hipErrorInvalidValue;
+    if (level_major & 4) {
+        // the two pointers address one tensor: logits start behind the slice's offsets
+        const int hps = channels == 16 ? 2 : 1;
+        if ((channels != 16 && channels != 32) || attn_logits != sampling_offsets + hps * num_point * 2 ||
+            offsets_query_stride != logits_query_stride || offsets_query_stride < dense_l + dense_w)
+            return (int)hipErrorInvalidValue;
+    }
     if (!value || !spatial_shapes || !level_start_index || !reference_points || !sampling_offsets || !attn_logits || !out)
         return (int)hipErrorInvalidValue;
     const bool a16 = ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(reference_points) |

@@ -106,10 +106,9 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         const bool active = ncam > 0 && qi < TH * TW && qy < Hq && qx < Wq;
         // per-lane part of the sampling-data addresses (cell, head); camera c adds (b*S + lsi[c]) queries
         const int64_t cell = active ? (int64_t)qy * Wq + qx : 0;
-        const float *lp0 = off + cell * lay.q_l + head * lay.h_l;
-        const float *wp0 = logit + cell * lay.q_w + head * lay.h_w;
-        constexpr int RPL = FUSED == 2 ? 2 : P * 2;         // floats of reference points per (query, level)
-        const float *rp0 = FUSED ? ref + b * ref_bstride + cell * L * RPL : nullptr;
+        const float *lp0 = off + cell * lay.q_l + lay.head_l(head);
+        const float *wp0 = logit + cell * lay.q_w + lay.head_w(head);
+        const float *rp0 = FUSED ? ref + b * ref_bstride + cell * lay.r_q : nullptr;
         auto cam_q = [&](int c) { return (int64_t)b * S + lsi[c]; };          // wave-uniform
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
 
@@ -171,11 +170,11 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     nb = *reinterpret_cast<const float4 *>(lp + 4);
                     nw = *reinterpret_cast<const float4 *>(wp0 + cq * lay.q_w + l * lay.l_w);
                     if constexpr (FUSED == 1) {
-                        const float *rp = rp0 + (cq - (int64_t)b * S) * L * P * 2 + l * P * 2;
+                        const float *rp = rp0 + (cq - (int64_t)b * S) * lay.r_q + l * lay.r_l;
                         nra = *reinterpret_cast<const float4 *>(rp);
                         nrb = *reinterpret_cast<const float4 *>(rp + 4);
                     } else if constexpr (FUSED == 2) {
-                        const float2 r = *reinterpret_cast<const float2 *>(rp0 + (cq - (int64_t)b * S) * L * 2 + l * 2);
+                        const float2 r = *reinterpret_cast<const float2 *>(rp0 + (cq - (int64_t)b * S) * lay.r_q + l * lay.r_l);
                         nra = nrb = make_float4(r.x, r.y, r.x, r.y);
                     }
                 };
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                 if (c >= ncam) continue;
                 const int64_t cq = cam_q(cam0 + c);
                 const float *lp = lp0 + cq * lay.q_l, *wp = wp0 + cq * lay.q_w;
-                const float *rp = FUSED ? rp0 + lsi[cam0 + c] * L * RPL : nullptr;
+                const float *rp = FUSED ? rp0 + lsi[cam0 + c] * lay.r_q : nullptr;
                 MissT mm = miss[c];
                 // taps that left the window: straight from global memory (zero padding by test)
                 while (mm) {
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     const float fW = (float)Wq, fH = (float)Hq;
                     float lx = lp[l * lay.l_l + pp * 2 + 0], ly = lp[l * lay.l_l + pp * 2 + 1], a = wp[l * lay.l_w + pp];
                     if constexpr (FUSED) {
-                        const int ri = FUSED == 2 ? l * 2 : bit * 2;
+                        const int ri = l * lay.r_l + (FUSED == 2 ? 0 : pp * 2);
                         lx = rp[ri + 0] + lx * (1.f / fW);
                         ly = rp[ri + 1] + ly * (1.f / fH);
                         a = __expf(a - smax[c]);

@@ -108,11 +108,9 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
                       int P, float *out, const int *local_hits)
 {
-    const SamplingLayout lay = {M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P};     // [.., Lq, M, L, P(, 2)]
+    const SamplingLayout lay = plain_layout(M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P);     // [.., Lq, M, L, P(, 2)]
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
-    if (msda_quad_supported(M, D, L) && !narrow_slices())
-        return msda_forward_quad(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
     if (msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
     return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out, local_hits);
@@ -123,19 +121,27 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
                             int layout, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
                             int M, int D, int L, float *out)
 {
-    const int level_major = layout & 1, shared_ref = layout & 2;
+    const int level_major = layout & 1, shared_ref = layout & 2, slice_major = layout & 4, ref_level_major = layout & 8;
     const int P = TILE_P;
-    const SamplingLayout lay = level_major
-        ? SamplingLayout{qstride_l, P * 2, M * P * 2, qstride_w, P, M * P}              // [.., Lq, L, M, P(, 2)]
-        : SamplingLayout{qstride_l, L * P * 2, P * 2, qstride_w, L * P, P};             // [.., Lq, M, L, P(, 2)]
+    // reference points: [.., Lq, L, P, 2], [.., Lq, L, 2] (shared_ref) or [.., L, Lq, 2] (shared_ref + ref_level_major)
+    const int r_q = ref_level_major ? 2 : L * (shared_ref ? 2 : P * 2);
+    const int r_l = ref_level_major ? Lq * 2 : (shared_ref ? 2 : P * 2);
+    SamplingLayout lay;
+    if (slice_major) {
+        // one tensor [.., Lq, M / hps, L, (hps x P x 2 offsets | hps x P logits)]: what the workgroup of a 128-byte
+        // slice reads for a (query, level) is one contiguous run of hps * 12 floats; `logits` = `offsets` + hps * 8
+        const int hps = 32 / D, chunk = hps * P * 3;
+        lay = SamplingLayout{qstride_l, P * 2, chunk, qstride_w, P, chunk, hps, L * chunk, L * chunk, r_q, r_l};
+    } else if (level_major) {
+        lay = plain_layout(qstride_l, P * 2, M * P * 2, qstride_w, P, M * P, r_q, r_l);              // [.., Lq, L, M, P(, 2)]
+    } else {
+        lay = plain_layout(qstride_l, L * P * 2, P * 2, qstride_w, L * P, P, r_q, r_l);              // [.., Lq, M, L, P(, 2)]
+    }
     // MVDeTr's camera counts: the camera-grouped kernel (which falls back to this file's tile body, in the
     // same launch, when the levels turn out on the device to have unequal shapes) -- msda_forward_group.hip
     // A query-sharded call (a rank's own cameras as queries, mvdetr_amd/dist.py) has too few query levels per
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
-    if (all_levels && msda_quad_supported(M, D, L) && !narrow_slices())
-        return msda_forward_quad(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
-                                 M, D, L, out);
     if (all_levels && msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
                                   M, D, L, out);

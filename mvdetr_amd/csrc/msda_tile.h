@@ -41,13 +41,26 @@ using CfgWide32 = TileCfg<32, 32, 8, 16, 6>;
 using CfgNarrow16 = TileCfg<16, 16, 8, 16, 6>;
 using CfgNarrow32 = TileCfg<32, 16, 8, 16, 6>;
 
-// Where element (query, head, level) of the sampling locations / weights starts: query * q + head * h +
-// level * l floats.  Covers the reference layout [.., Lq, M, L, P(, 2)] and the fused path's level-major and
-// column-block layouts; filled in by the host.
+// Where element (query, head, level) of the sampling locations / weights starts, in floats:
+//     query * q + (head / hps) * s + (head % hps) * h + level * l
+// hps > 1 groups the heads whose channels one workgroup stages together (a 128-byte slice of the token row): the
+// fused path's slice-interleaved layout keeps everything ONE workgroup reads for a (query, level) -- offsets and
+// logits of its hps heads -- in one contiguous run, so that a 128-byte line is not fetched for a quarter of its
+// bytes.  Plain layouts have hps = 1, s = h.  Covers the reference layout [.., Lq, M, L, P(, 2)] and the fused path's
+// level-major, column-block and slice-interleaved layouts; filled in by the host.
+// Reference points: query * r_q + level * r_l (+ 2 * point when there is one per point).
 struct SamplingLayout {
     int q_l, h_l, l_l;      // locations (or raw offsets)
     int q_w, h_w, l_w;      // weights (or raw logits)
+    int hps, s_l, s_w;      // head grouping (see above)
+    int r_q, r_l;           // reference points
+    __host__ __device__ int head_l(int head) const { return (head / hps) * s_l + (head % hps) * h_l; }
+    __host__ __device__ int head_w(int head) const { return (head / hps) * s_w + (head % hps) * h_w; }
 };
+inline SamplingLayout plain_layout(int q_l, int h_l, int l_l, int q_w, int h_w, int l_w, int r_q = 0, int r_l = 0)
+{
+    return SamplingLayout{q_l, h_l, l_l, q_w, h_w, l_w, 1, h_l, h_w, r_q, r_l};
+}
 
 // Which levels' tokens are the queries of a call: [begin, end) of the L levels, Lq tokens in all.
 struct QueryLevels {
@@ -62,12 +75,6 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out,
                        const int *local_hits = nullptr);
-
-// camera-grouped forward with a quad of lanes per (cell, head) (msda_forward_quad.hip); same contract as above
-bool msda_quad_supported(int M, int D, int L);
-int msda_forward_quad(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi, const float *off,
-                      const float *logit, const float *ref, int64_t ref_bstride, int fused, SamplingLayout lay, int B,
-                      int S, int M, int D, int L, float *out, const int *local_hits = nullptr);
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
 // scalar registers).

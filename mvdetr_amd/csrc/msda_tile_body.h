@@ -126,10 +126,10 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
         // instances of it; the host fills the strides in.
         const int lstep_l = lay.l_l, lstep_w = lay.l_w;
         const int64_t bq = active ? (int64_t)b * Lq + q : 0;
-        const float *lp = loc + bq * lay.q_l + head * lay.h_l;
-        const float *wp = aw + bq * lay.q_w + head * lay.h_w;
-        constexpr int RPL = FUSED == 2 ? 2 : P * 2;         // floats of reference points per (query, level)
-        const float *rp = FUSED ? ref + b * ref_bstride + (active ? q : 0) * L * RPL : nullptr;
+        const float *lp = loc + bq * lay.q_l + lay.head_l(head);
+        const float *wp = aw + bq * lay.q_w + lay.head_w(head);
+        const int rstep = lay.r_l;                            // floats of reference points from level to level
+        const float *rp = FUSED ? ref + b * ref_bstride + (active ? q : 0) * lay.r_q : nullptr;
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;   // this slice of token 0
 
         float2v acc[2 * NV];
@@ -177,10 +177,10 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
             b2 = *reinterpret_cast<const float4 *>(lp + l * lstep_l + 4);
             w = *reinterpret_cast<const float4 *>(wp + l * lstep_w);
             if constexpr (FUSED == 1) {
-                r0 = *reinterpret_cast<const float4 *>(rp + l * P * 2);
-                r1 = *reinterpret_cast<const float4 *>(rp + l * P * 2 + 4);
+                r0 = *reinterpret_cast<const float4 *>(rp + l * rstep);
+                r1 = *reinterpret_cast<const float4 *>(rp + l * rstep + 4);
             } else if constexpr (FUSED == 2) {
-                const float2 r = *reinterpret_cast<const float2 *>(rp + l * 2);
+                const float2 r = *reinterpret_cast<const float2 *>(rp + l * rstep);
                 r0 = r1 = make_float4(r.x, r.y, r.x, r.y);
             }
         };
@@ -319,7 +319,7 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
                 const int pp = bit - l * P;
                 float lx = lp[l * lstep_l + pp * 2 + 0], ly = lp[l * lstep_l + pp * 2 + 1], a = wp[l * lstep_w + pp];
                 if constexpr (FUSED) {
-                    const int ri = FUSED == 2 ? l * 2 : bit * 2;
+                    const int ri = l * rstep + (FUSED == 2 ? 0 : pp * 2);
                     lx = rp[ri + 0] + lx * (1.f / (float)W);
                     ly = rp[ri + 1] + ly * (1.f / (float)H);
                     a = __expf(a - smax);                  // un-normalised, like the accumulators

@@ -135,8 +135,12 @@ class QueryShardedFusion:
         wf, own = self.wf, self.own_slice(h, w)
         B = src_own.shape[0]
         ref = wf.encoder.reference_points[own].unsqueeze(0).expand(B, -1, -1, -1, -1)
+        shared = wf.encoder.reference_shared
+        if shared is not None:
+            shared = shared[:, own].unsqueeze(0)                 # level-major [1, L, own queries, 2]
         return wf.encoder.layers[i](src_own, wf.level_pos(h, w)[:, own], ref, wf.spatial_shapes,
-                                    wf.level_start_index, query_levels=(s, e), projected_value=value_all)
+                                    wf.level_start_index, query_levels=(s, e), projected_value=value_all,
+                                    shared_reference=shared)
 
     def merge_partial(self, src_own, B, h, w):
         """This rank's cameras' term of merge_linear's 1x1 convolution (no bias), [B, C, h, w]."""

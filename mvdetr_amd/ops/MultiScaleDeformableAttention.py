@@ -105,52 +105,95 @@ def fused_supported_dims(B, S, M, D, num_levels, num_query, num_point, query_lev
 
 
 def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                                 attn_logits, level_major=False, query_levels=None):
+                                 attn_logits, level_major=False, query_levels=None, *, raw=None, ref_level_major=False):
     """Core + the module arithmetic around it (ms_deform_attn.py:100-107) in one kernel (inference):
     value [B,S,M,D]; reference_points [B or 1, Lq, L, P, 2] (may be a batch-expanded view), or [B or 1, Lq, L, 2]
-    when the P sampling points of a (query, level) share one reference point (MVDeTr's map: P identical copies);
+    when the P sampling points of a (query, level) share one reference point (MVDeTr's map: P identical copies) --
+    that form may also be level-major, [B or 1, L, Lq, 2], with ``ref_level_major``;
     sampling_offsets [B,Lq,M,L,P,2] and attn_logits [B,Lq,M,L,P] are the raw Linear outputs
     ([B,Lq,L,M,P,2] / [B,Lq,L,M,P] with ``level_major``); each may be a column block of a wider GEMM
-    output (dense per query, arbitrary query stride).  -> [B, Lq, M*D].
+    output (dense per query, arbitrary query stride).  Alternatively ``raw`` [B, Lq, M/g * L * 12g] holds both,
+    slice-interleaved (g = 32/D heads per 128-byte slice of the token row; per (query, slice, level): g*P*2 offsets
+    then g*P logits -- see slice_major_rows()); sampling_offsets / attn_logits are then None.  -> [B, Lq, M*D].
     ``query_levels=(l0, l1)``: the Lq queries are the tokens of levels l0..l1-1 only (one rank's cameras in a
     query-sharded encoder, mvdetr_amd/dist.py); value still holds every level.
     No extension counterpart in the reference: this is SURVEY row f1."""
     _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index)])
     B, S, M, D = value.shape
-    L, Lq, P = spatial_shapes.shape[0], sampling_offsets.shape[1], sampling_offsets.shape[4]
-    if tuple(sampling_offsets.shape[2:4]) != ((L, M) if level_major else (M, L)):
-        raise RuntimeError("sampling_offsets layout does not match level_major")
-    qstrides = []
-    for name, t, inner in (("sampling_offsets", sampling_offsets, M * L * P * 2), ("attn_logits", attn_logits, M * L * P)):
-        if not t.is_cuda or t.dtype != value.dtype:
-            raise RuntimeError(f"{name} must be a CUDA tensor of value's dtype")
-        flat = t.reshape(B, Lq, inner) if t.is_contiguous() else t
-        if not t.is_contiguous():
-            # accept a column block [..., a:b] of a [B, Lq, K] GEMM output, viewed as [B, Lq, ., ., .(, 2)]
-            st = t.stride()
-            dense_inner = all(st[i] == st[i + 1] * t.shape[i + 1] for i in range(2, t.dim() - 1)) and st[-1] == 1
-            if not dense_inner or (B > 1 and st[0] != st[1] * Lq):
-                raise RuntimeError(f"{name} tensor has to be contiguous per query")
-        qstrides.append(t.stride(1))
+    L = spatial_shapes.shape[0]
+    flags = 0
+    if raw is not None:
+        if sampling_offsets is not None or attn_logits is not None or level_major:
+            raise RuntimeError("raw (slice-interleaved) excludes sampling_offsets / attn_logits / level_major")
+        if D not in (16, 32):
+            raise RuntimeError("the slice-interleaved layout exists for 16 or 32 channels per head")
+        P = 4
+        Lq = raw.shape[1]
+        if (raw.dim() != 3 or raw.shape[0] != B or raw.shape[2] < M * L * P * 3 or not raw.is_cuda or raw.dtype != value.dtype
+                or raw.stride(2) != 1 or (B > 1 and raw.stride(0) != raw.stride(1) * Lq)):
+            raise RuntimeError("raw must be a CUDA tensor [B, Lq, >= M*L*P*3] of value's dtype, dense per query")
+        g = 32 // D
+        off_ptr, logit_ptr = raw.data_ptr(), raw.data_ptr() + g * P * 2 * raw.element_size()
+        qstrides = [raw.stride(1), raw.stride(1)]
+        flags |= 4
+    else:
+        Lq, P = sampling_offsets.shape[1], sampling_offsets.shape[4]
+        if tuple(sampling_offsets.shape[2:4]) != ((L, M) if level_major else (M, L)):
+            raise RuntimeError("sampling_offsets layout does not match level_major")
+        qstrides = []
+        for name, t, inner in (("sampling_offsets", sampling_offsets, M * L * P * 2), ("attn_logits", attn_logits, M * L * P)):
+            if not t.is_cuda or t.dtype != value.dtype:
+                raise RuntimeError(f"{name} must be a CUDA tensor of value's dtype")
+            if not t.is_contiguous():
+                # accept a column block [..., a:b] of a [B, Lq, K] GEMM output, viewed as [B, Lq, ., ., .(, 2)]
+                st = t.stride()
+                dense_inner = all(st[i] == st[i + 1] * t.shape[i + 1] for i in range(2, t.dim() - 1)) and st[-1] == 1
+                if not dense_inner or (B > 1 and st[0] != st[1] * Lq):
+                    raise RuntimeError(f"{name} tensor has to be contiguous per query")
+            qstrides.append(t.stride(1))
+        off_ptr, logit_ptr = sampling_offsets.data_ptr(), attn_logits.data_ptr()
+        flags |= 1 if level_major else 0
     shared_ref = reference_points.dim() == 4
-    if (reference_points.shape[1:] != ((Lq, L, 2) if shared_ref else (Lq, L, P, 2)) or not reference_points.is_cuda
+    if ref_level_major and not shared_ref:
+        raise RuntimeError("ref_level_major needs one reference point per (query, level)")
+    want = ((L, Lq, 2) if ref_level_major else (Lq, L, 2)) if shared_ref else (Lq, L, P, 2)
+    if (tuple(reference_points.shape[1:]) != want or not reference_points.is_cuda
             or reference_points.dtype != value.dtype or reference_points.shape[0] not in (1, B)):
-        raise RuntimeError("reference_points must be a CUDA tensor of shape [B or 1, Lq, L, P, 2] or [B or 1, Lq, L, 2]")
+        raise RuntimeError("reference_points must be a CUDA tensor of shape [B or 1, Lq, L, P, 2], [B or 1, Lq, L, 2] "
+                           "or (ref_level_major) [B or 1, L, Lq, 2]")
     if not reference_points[0].is_contiguous():
         reference_points = reference_points.contiguous()
     rstride = reference_points.stride(0) if reference_points.shape[0] > 1 else 0
+    flags |= (2 if shared_ref else 0) | (8 if ref_level_major else 0)
     _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)
     l0, l1 = (0, L) if query_levels is None else (int(query_levels[0]), int(query_levels[1]))
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
     with torch.cuda.device(value.device):
         rc = _lib.lib().mvdetr_msda_forward_fused_levels_f32(
             _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
-            level_start_index.data_ptr(), reference_points.data_ptr(), rstride, sampling_offsets.data_ptr(),
-            attn_logits.data_ptr(), (1 if level_major else 0) | (2 if shared_ref else 0), qstrides[0], qstrides[1], l0, l1,
-            B, S, M, D, L, Lq,
-            P, out.data_ptr())
+            level_start_index.data_ptr(), reference_points.data_ptr(), rstride, off_ptr, logit_ptr, flags,
+            qstrides[0], qstrides[1], l0, l1, B, S, M, D, L, Lq, P, out.data_ptr())
     _lib.check(rc, "ms_deform_attn_forward_fused")
     return out
+
+
+def slice_major_rows(M, L, P, D):
+    """Row order of the ONE Linear that produces the slice-interleaved ``raw`` tensor from the reference module's two:
+    (rows of sampling_offsets.weight, rows of attention_weights.weight shifted by M*L*P*2), i.e. indices into
+    cat([sampling_offsets.weight, attention_weights.weight]).  Reference row orders: offsets (m, l, p, xy),
+    logits (m, l, p) -- ms_deform_attn.py:99-101."""
+    g = 32 // D
+    n_off = M * L * P * 2
+    rows = []
+    for s in range(M // g):
+        for l in range(L):
+            for h in range(g):
+                m = s * g + h
+                rows += [((m * L + l) * P + p) * 2 + xy for p in range(P) for xy in range(2)]
+            for h in range(g):
+                m = s * g + h
+                rows += [n_off + (m * L + l) * P + p for p in range(P)]
+    return rows
 
 
 def last_forward_impl() -> str:

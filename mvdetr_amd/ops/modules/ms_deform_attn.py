@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import warnings
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -46,7 +47,11 @@ class MSDeformAttn(nn.Module):
         self._shared_ref_cache = None
         # inference calls of deformable-encoder shape run softmax + location arithmetic inside the kernel
         self.fused_inference = True
+        # the permuted [offsets | logits] weight of the fused path is rebuilt on every call unless the owner declares
+        # the parameters frozen (cache_fused_projection(True)): a cache cannot see writes through .data
+        self._cache_projection = False
         self._fused_cache = None
+        self._fused_rows = None
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -67,22 +72,31 @@ class MSDeformAttn(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight.data)
         nn.init.constant_(self.output_proj.bias.data, 0.0)
 
+    def cache_fused_projection(self, enable=True):
+        """Inference deployments with frozen parameters: keep the fused path's permuted weight instead of rebuilding it
+        (two small gathers) on every call.  Call again, or with False, after changing sampling_offsets /
+        attention_weights in ANY way -- writes through ``.data`` (EMA swaps, constant_(w.data)) are invisible to a cache."""
+        self._cache_projection = bool(enable)
+        self._fused_cache = None
+        return self
+
     def _fused_projection(self):
-        """Weights of ONE Linear producing [offsets | logits] with output rows reordered from the reference's
-        (head, level, point) to (level, head, point): a free change of the output layout that lets the kernel
-        read what one level iteration needs from the same cache lines.  Cached until a parameter changes."""
-        ps = (self.sampling_offsets.weight, self.sampling_offsets.bias, self.attention_weights.weight,
-              self.attention_weights.bias)
-        key = tuple((p.data_ptr(), p._version) for p in ps)
-        if self._fused_cache is None or self._fused_cache[0] != key:
-            M, L, P, C = self.n_heads, self.n_levels, self.n_points, self.d_model
-            with torch.no_grad():
-                ow = ps[0].view(M, L, P * 2, C).transpose(0, 1).reshape(M * L * P * 2, C)
-                ob = ps[1].view(M, L, P * 2).transpose(0, 1).reshape(-1)
-                aw = ps[2].view(M, L, P, C).transpose(0, 1).reshape(M * L * P, C)
-                ab = ps[3].view(M, L, P).transpose(0, 1).reshape(-1)
-                self._fused_cache = (key, torch.cat([ow, aw], 0).contiguous(), torch.cat([ob, ab], 0).contiguous())
-        return self._fused_cache[1], self._fused_cache[2]
+        """Weight and bias of ONE Linear producing the fused kernel's slice-interleaved raw tensor: the rows of the
+        reference's two Linears (offsets (m, l, p, xy), logits (m, l, p); ms_deform_attn.py:55-56) reordered by
+        MSDA.slice_major_rows -- a free change of the output layout that puts what one workgroup reads for a
+        (query, level) into one contiguous run."""
+        if self._cache_projection and self._fused_cache is not None:
+            return self._fused_cache
+        dev = self.sampling_offsets.weight.device
+        if self._fused_rows is None or self._fused_rows.device != dev:
+            rows = MSDA.slice_major_rows(self.n_heads, self.n_levels, self.n_points, self.d_model // self.n_heads)
+            self._fused_rows = torch.tensor(rows, dtype=torch.long, device=dev)
+        with torch.no_grad():
+            w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).index_select(0, self._fused_rows)
+            b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).index_select(0, self._fused_rows)
+        if self._cache_projection:
+            self._fused_cache = (w, b)
+        return w, b
 
     def _check_lengths(self, spatial_shapes, len_in):
         # the reference asserts sum(H*W) == Len_in on every call (ms_deform_attn.py:94), which is a
@@ -102,17 +116,22 @@ class MSDeformAttn(nn.Module):
         return value
 
     def _shared_reference(self, reference_points):
-        """[N, Lq, L, P, 2] -> contiguous [1 or N, Lq, L, 2] when the P points of every (query, level) are the same
-        point (MVDeTr's reference map, mvdetr.py:49-58 with all heights 0), else None.  Checked once per tensor
-        (one device sync) and cached: the fused kernel then loads a quarter of the reference bytes."""
-        key = (reference_points.data_ptr(), reference_points._version, tuple(reference_points.shape),
-               reference_points.stride())
-        if self._shared_ref_cache is None or self._shared_ref_cache[0] != key:
+        """[N, Lq, L, P, 2] -> level-major [1 or N, L, Lq, 2] when the P points of every (query, level) are the same
+        point (MVDeTr's reference map, mvdetr.py:49-58 with all heights 0), else None.  The test costs a device
+        sync, so its verdict is remembered -- for that tensor OBJECT (weak reference + version counter), never for an
+        address: the caching allocator hands a freed address to the next tensor of the same shape.  Callers that build
+        a new view every forward pass ``shared_reference`` to forward() instead (mvdetr_amd/world_feat.py does)."""
+        c = self._shared_ref_cache
+        if c is not None and c[0]() is reference_points and c[1] == reference_points._version:
+            same = c[2]
+        else:
             ref = reference_points[:1] if reference_points.stride(0) == 0 else reference_points
-            first = ref[..., :1, :]
-            same = bool((ref == first).all())
-            self._shared_ref_cache = (key, first.squeeze(-2).contiguous() if same else None)
-        return self._shared_ref_cache[1]
+            same = bool((ref == ref[..., :1, :]).all())
+            self._shared_ref_cache = (weakref.ref(reference_points), reference_points._version, same)
+        if not same:
+            return None
+        ref = reference_points[:1] if reference_points.stride(0) == 0 else reference_points
+        return ref[..., 0, :].transpose(1, 2).contiguous()                   # rebuilt from the live tensor every time
 
     def _check_query_levels(self, spatial_shapes, query_levels, len_q):
         key = (spatial_shapes.data_ptr(), spatial_shapes._version, tuple(query_levels), len_q)
@@ -123,7 +142,8 @@ class MSDeformAttn(nn.Module):
             self._validated_q = key
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None, *, query_levels=None, projected_value=None):
+                input_level_start_index, input_padding_mask=None, *, query_levels=None, projected_value=None,
+                shared_reference=None):
         """query (N, Lq, C); reference_points (N, Lq, n_levels, n_points, 2) in [0,1] -- MVDeTr's 5-D
         form (ms_deform_attn.py:104-107) -- or (..., 4) boxes; input_flatten (N, sum H_l*W_l, C);
         input_spatial_shapes (n_levels, 2); input_level_start_index (n_levels,);
@@ -132,7 +152,9 @@ class MSDeformAttn(nn.Module):
         Two keyword extensions for the query-sharded encoder (not in the reference): ``projected_value``
         (N, sum H_l*W_l, C) = project_value() of all tokens, used instead of projecting ``input_flatten`` here;
         ``query_levels=(l0, l1)`` promises that the Lq queries are exactly the tokens of levels l0..l1-1, which
-        lets the fused kernel take the call (it is only a hint: results do not depend on it)."""
+        lets the fused kernel take the call (it is only a hint: results do not depend on it).
+        ``shared_reference`` (N or 1, n_levels, Lq, 2): the caller's promise that the n_points reference points of every
+        (query, level) coincide, with that point level-major -- saves the module its own test (a device sync)."""
         N, Len_q, _ = query.shape
         M, D = self.n_heads, self.d_model // self.n_heads
         # ``projected_value`` may also be a zero-argument callable returning the tensor, with a ``length`` attribute
@@ -149,32 +171,48 @@ class MSDeformAttn(nn.Module):
         self._check_lengths(input_spatial_shapes, Len_in)
         if query_levels is not None:
             self._check_query_levels(input_spatial_shapes, query_levels, Len_q)
-        needs_grad = torch.is_grad_enabled() and ((value is not None and value.requires_grad) or query.requires_grad
-                                                  or self.sampling_offsets.weight.requires_grad)
+        needs_grad = torch.is_grad_enabled() and (query.requires_grad or (value is not None and value.requires_grad)
+                                                  or any(p.requires_grad for p in self.parameters()))
         if (self.fused_inference and reference_points.shape[-1] == 2 and reference_points.dim() == 5
-                and not needs_grad and query.is_cuda and query.dtype == torch.float32
+                and not needs_grad and query.is_cuda and query.dtype == torch.float32 and D in (16, 32)
                 and (value is None or (value.is_cuda and value.dtype == torch.float32))
+                and (pending is None or getattr(pending, "dtype", torch.float32) == torch.float32)
+                and reference_points.is_cuda and reference_points.dtype == torch.float32
                 and MSDA.fused_supported_dims(N, Len_in, M, D, self.n_levels, Len_q, self.n_points, query_levels)):
-            # one GEMM for offsets + logits, rows permuted to level-major (see _fused_projection)
+            # one GEMM for offsets + logits, rows permuted to the slice-interleaved layout (see _fused_projection)
             w, b = self._fused_projection()
             raw = F.linear(query, w, b)
             if pending is not None:
                 value = pending()
-            value = value.view(N, Len_in, M, D)
+            value = value.view(N, Len_in, M, D).contiguous()
+            shared = shared_reference if shared_reference is not None else self._shared_reference(reference_points)
+            if value.data_ptr() % 16 == 0 and raw.data_ptr() % 16 == 0:      # (the kernel's alignment contract)
+                out = MSDA.ms_deform_attn_forward_fused(
+                    value, input_spatial_shapes, input_level_start_index,
+                    reference_points if shared is None else shared, None, None, query_levels=query_levels, raw=raw,
+                    ref_level_major=shared is not None)
+                return self.output_proj(out)
+            # odd storage offsets: the reference arithmetic on the same raw values
             n_off = self.n_heads * self.n_levels * self.n_points * 2
-            L, M, P = self.n_levels, self.n_heads, self.n_points
-            shared = self._shared_reference(reference_points)
-            out = MSDA.ms_deform_attn_forward_fused(
-                value.contiguous(), input_spatial_shapes, input_level_start_index,
-                reference_points if shared is None else shared,
-                raw[..., :n_off].unflatten(-1, (L, M, P, 2)), raw[..., n_off:].unflatten(-1, (L, M, P)),
-                level_major=True, query_levels=query_levels)
-            return self.output_proj(out)
+            inv = torch.empty_like(self._fused_rows)
+            inv[self._fused_rows] = torch.arange(inv.numel(), device=inv.device)
+            plain = raw.index_select(-1, inv)
+            offsets = plain[..., :n_off].reshape(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+            weights = plain[..., n_off:].reshape(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+            return self._reference_core(value, offsets, weights, reference_points, input_spatial_shapes,
+                                        input_level_start_index, N, Len_q)
         if pending is not None:
             value = pending()
         value = value.view(N, Len_in, M, D)
         offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        return self._reference_core(value, offsets, weights, reference_points, input_spatial_shapes,
+                                    input_level_start_index, N, Len_q)
+
+    def _reference_core(self, value, offsets, weights, reference_points, input_spatial_shapes,
+                        input_level_start_index, N, Len_q):
+        """ms_deform_attn.py:100-117 from the raw offsets / logits on: softmax, sampling locations, the extension's
+        differentiable function, output projection."""
         weights = F.softmax(weights, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
@@ -186,6 +224,6 @@ class MSDeformAttn(nn.Module):
         else:
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
                              .format(reference_points.shape[-1]))
-        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+        out = MSDeformAttnFunction.apply(value.contiguous(), input_spatial_shapes, input_level_start_index,
                                          locations.contiguous(), weights, self.im2col_step)
         return self.output_proj(out)

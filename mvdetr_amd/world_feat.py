@@ -69,7 +69,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, *,
-                query_levels=None, projected_value=None, query=None, next_pos=None):
+                query_levels=None, projected_value=None, query=None, next_pos=None, shared_reference=None):
         """deformable_transformer.py:88-100.  With ``projected_value`` (self_attn.project_value of ALL tokens)
         ``src``/``pos``/``reference_points`` may hold only the queries of levels ``query_levels`` -- one rank's
         share of a query-sharded layer (mvdetr_amd/dist.py); the layer is per-token apart from the attention.
@@ -77,7 +77,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
         next layer's query) -- the encoder uses both to fold the position add into the LayerNorm pass."""
         attn = self.self_attn(self.with_pos_embed(src, pos) if query is None else query, reference_points, src, spatial_shapes,
                               level_start_index, padding_mask, query_levels=query_levels,
-                              projected_value=projected_value)
+                              projected_value=projected_value, shared_reference=shared_reference)
         # eval mode on the GPU: residual add + LayerNorm in one HIP pass (dropout is the identity there);
         # training keeps the reference's differentiable torch ops
         if not self.training and fused_add_layer_norm_available(src, self.norm1):
@@ -98,8 +98,13 @@ class DeformableTransformerEncoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
         self.num_layers = num_layers
+        self.register_buffer("reference_shared", None, persistent=False)
         if reference_points is not None:
             self.register_buffer("reference_points", reference_points, persistent=False)
+            # MVDeTr's map repeats one point n_points times (mvdetr.py:49-58 with all heights 0): tell the attention
+            # modules so (level-major [L, Lq, 2]; they would otherwise test it themselves, a device sync per new view)
+            if bool((reference_points == reference_points[..., :1, :]).all()):
+                self.reference_shared = reference_points[..., 0, :].transpose(0, 1).contiguous()
         else:
             self.reference_points = None
 
@@ -109,13 +114,15 @@ class DeformableTransformerEncoder(nn.Module):
                              "default of Deformable-DETR is not part of this contract "
                              "(ms_deform_attn.py:104-107)")
         ref = self.reference_points.unsqueeze(0).expand(src.shape[0], -1, -1, -1, -1)
+        shared = None if self.reference_shared is None else self.reference_shared.unsqueeze(0)
         out, query = src, None
         for i, layer in enumerate(self.layers):
             if pos is not None and i + 1 < self.num_layers:
                 out, query = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask, query=query,
-                                   next_pos=pos)                 # the next layer's src + pos comes with the LayerNorm
+                                   next_pos=pos, shared_reference=shared)   # the next layer's src + pos comes with the LayerNorm
             else:
-                out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask, query=query)
+                out = layer(out, pos, ref, spatial_shapes, level_start_index, padding_mask, query=query,
+                            shared_reference=shared)
         return out
 
 

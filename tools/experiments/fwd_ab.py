@@ -72,6 +72,19 @@ def main():
         err = (fn() - ref_out).abs().max().item()
         avg, med, mn = time_us(fn, a.iters)
         print(f"fused    noise {noise:3.1f}px  avg {avg:7.1f} med {med:7.1f} min {mn:7.1f} us  {nbytes / avg * 1e6 / 8e12 * 100:5.1f}%  err_vs_gather {err:.2e}", flush=True)
+        # slice-interleaved raw tensor + level-major reference points (what the module feeds the kernel)
+        rows = torch.tensor(MSDA.slice_major_rows(M, L, P, D), device="cuda")
+        plain = torch.cat([off.reshape(B, S, -1), logit.reshape(B, S, -1)], -1)
+        raw_s = plain.index_select(-1, rows).contiguous()
+        ref_lm = ref4.transpose(1, 2).contiguous()
+        fn = lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, ref_lm, None, None, raw=raw_s, ref_level_major=True)  # noqa: E731
+        err = (fn() - ref_out).abs().max().item()
+        avg, med, mn = time_us(fn, a.iters)
+        print(f"fused-sl noise {noise:3.1f}px  avg {avg:7.1f} med {med:7.1f} min {mn:7.1f} us  {nbytes / avg * 1e6 / 8e12 * 100:5.1f}%  err_vs_gather {err:.2e}", flush=True)
+        fn = lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, ref4, None, None, raw=raw_s)  # noqa: E731
+        err = (fn() - ref_out).abs().max().item()
+        avg, med, mn = time_us(fn, a.iters)
+        print(f"fused-sl(ref q-major) {noise:3.1f}px  avg {avg:7.1f} med {med:7.1f} min {mn:7.1f} us  {nbytes / avg * 1e6 / 8e12 * 100:5.1f}%  err_vs_gather {err:.2e}", flush=True)
 
 
 if __name__ == "__main__":

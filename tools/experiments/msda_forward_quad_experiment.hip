@@ -1,3 +1,10 @@
+// EXPERIMENT, NOT BUILT (round 2): a camera-grouped forward with the work of one (cell, head) spread over a quad of
+// lanes.  Correct (1e-6 against the gather kernel) and free of LDS bank conflicts by construction, but not faster than
+// msda_forward_group.hip: 180-190 us against 151 us at Wildtrack size.  What the measurements around it showed is the
+// useful part: the forward kernels are bound by the rate at which a CU's L1 can miss --
+// about one 128-byte line per 13 cycles -- not by VALU issue, LDS bandwidth or occupancy.  This version issues its
+// loads from inline asm with hand-counted s_waitcnt; tools/experiments/check_quad_asm.py shows why that is unsafe
+// (hipcc copies an asm load's destination register before the data has landed).
 // Multi-scale deformable attention forward, camera-grouped "quad" kernel -- gfx950 (MI355X).
 //
 // Same job as msda_forward_group.hip -- one workgroup owns a (6 x 16 cell tile, 128-byte slice) and walks all

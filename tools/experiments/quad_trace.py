@@ -25,10 +25,11 @@ buf = (ctypes.c_ulonglong * 1024)()
 lib.mvdetr_debug_quad_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 rc = lib.mvdetr_debug_quad_trace(buf, 1024)
 t = list(buf)
-t0 = t[0]
-names = ["start", "issued", "cam1", "cam4", "taps_done", "committed", "barrier"]
-for step in range(14):
-    row = t[step * 8: step * 8 + 7]
-    if not row[0]:
-        break
-    print(f"step {step:2d} @ {(row[0] - t0) / 100:8.2f} us: " + "  ".join(f"{n}+{(row[i] - row[0]) / 100:6.2f}" for i, n in enumerate(names) if i))
+t0 = min(x for x in t if x)
+for l in range(L):
+    print(f"level {l}")
+    for w in range(12):
+        row = t[w * 80 + l * 11: w * 80 + l * 11 + 11]
+        if not row[0]:
+            continue
+        print(f"  wave {w:2d}: arrive {(row[0] - t0) / 100:7.2f}  bar1 +{(row[1] - row[0]) / 100:5.2f}  copy +{(row[2] - row[1]) / 100:5.2f}  bar2 +{(row[3] - row[2]) / 100:5.2f}  cams " + " ".join(f"{(row[4 + c] - row[3 + c]) / 100:5.2f}" for c in range(7)))

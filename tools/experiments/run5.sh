@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 cp tools/experiments/lib_trace.so mvdetr_amd/csrc/libmvdetr_ops.so
-python tools/experiments/quad_trace.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r2/quad_trace.txt
+python tools/experiments/quad_trace.py 2>&1 | grep -v amdgpu.ids | tee $GRAFT_REPO_ROOT/gpurun_out/quad_trace.txt
