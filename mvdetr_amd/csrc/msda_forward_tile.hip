@@ -111,6 +111,8 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
     const SamplingLayout lay = plain_layout(M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P);     // [.., Lq, M, L, P(, 2)]
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
+    if (msda_quad_supported(M, D, L) && !narrow_slices())
+        return msda_forward_quad(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
     if (msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
     return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out, local_hits);
@@ -142,6 +144,9 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     // A query-sharded call (a rank's own cameras as queries, mvdetr_amd/dist.py) has too few query levels per
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
+    if (all_levels && msda_quad_supported(M, D, L) && !narrow_slices())
+        return msda_forward_quad(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
+                                 M, D, L, out);
     if (all_levels && msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
                                   M, D, L, out);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timeline of one workgroup of msda_fwd_quad (needs a -DMVDETR_QUAD_TRACE build of the library)."""
+"""Phase timeline of one workgroup of msda_fwd_group (needs a -DMVDETR_GROUP_TRACE build of the library)."""
 import ctypes
 import os
 import sys
@@ -22,15 +22,16 @@ for _ in range(5):
 torch.cuda.synchronize()
 lib = _lib.lib()
 buf = (ctypes.c_ulonglong * 2048)()
-lib.mvdetr_debug_quad_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
-lib.mvdetr_debug_quad_trace(buf, 2048)
+lib.mvdetr_debug_group_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.mvdetr_debug_group_trace(buf, 2048)
 t = list(buf)
 t0 = min(x for x in t if x)
 for l in range(L):
     print(f"level {l}")
-    for w in range(12):
+    for w in range(4):
         r = t[w * 128 + l * 16: w * 128 + l * 16 + 16]
         if not r[0]:
             continue
-        print(f"  wave {w:2d}: start {(r[0] - t0) / 100:7.2f}  cams " + " ".join(f"{(r[2 + c] - (r[1 + c] if c else r[0])) / 100:5.2f}" for c in range(7))
-              + f"  taps_done +{(r[9] - r[0]) / 100:5.2f}  barrier +{(r[10] - r[9]) / 100:5.2f}")
+        d = lambda a, b: (r[b] - r[a]) / 100 if r[a] and r[b] else float("nan")  # noqa: E731
+        print(f"  wave {w}: arrive {(r[0] - t0) / 100:7.2f}  bar1 +{d(0, 1):5.2f}  issue +{d(1, 2):5.2f}  landed +{d(2, 3):5.2f}  written +{d(3, 4):5.2f}  "
+              f"bar2 +{d(4, 5):5.2f}  cams " + " ".join(f"{d(5 + c, 6 + c):5.2f}" for c in range(7)))
