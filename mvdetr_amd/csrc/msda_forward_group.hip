@@ -42,7 +42,7 @@ template <> struct MissMask<true> { using type = unsigned long long; };
 // SPLIT > 1: the workgroup has SPLIT lane groups of TH*TW*2 lanes each; all use the same staged window, group g
 // takes the cameras [g*NGA, (g+1)*NGA) with NGA = ceil(NG/SPLIT) -- NGA accumulator sets per lane instead of NG,
 // which is what makes many-camera rigs (16 cameras: 4 groups x 4) fit the register file at all.
-template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1>
+template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1, bool DMA = false>
 __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
@@ -73,6 +73,11 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
             return;
         }
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
+    // level size and its reciprocal once, in scalar registers (left inside the tap loop the two IEEE divisions were
+    // re-done for every camera of every level)
+    const float fW = (float)Wq, fH = (float)Hq;
+    const float iw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.f / fW)));
+    const float ih = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.f / fH)));
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
     const int jobs = per_level * HS * B, jobs8 = (jobs + 7) / 8;
 
@@ -127,10 +132,31 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         for (int l = 0; l < L; ++l) {
             // window of level l around the tile (all levels have the query level's shape)
             const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
-            const float fW = (float)Wq, fH = (float)Hq, iw = 1.f / fW, ih = 1.f / fH;
             const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
             __syncthreads();                                  // everyone is done reading the old window
-            {
+            if constexpr (DMA) {
+                // LDS-DMA (buffer_load ... lds): a wave's 64 lanes are the 8 x 16-byte chunks of 8 consecutive window
+                // positions (row-major), i.e. 1 KB contiguous in LDS behind a wave-uniform base -- no staging registers,
+                // no ds_write; positions outside the level are out-of-range reads and store zeros.
+                const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(vbatch), 0, (int)((unsigned)S * row * 4u - (unsigned)(hs * SLICE) * 4u), 0x00020000);
+                const int gx = ox + my_col;
+                const bool xok = (unsigned)gx < (unsigned)Wq;
+                const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const unsigned so = (unsigned)((int)lsi[l] * row) * 4u;
+                if (col_ok) {
+#pragma unroll
+                    for (int i = 0; i < NSTAGE; ++i) {
+                        const int wy = my_row0 + i * RPP, gy = oy + wy;
+                        if (wy < WH) {
+                            const unsigned vo = (xok && (unsigned)gy < (unsigned)Hq) ? (unsigned)((gy * Wq + gx) * row + my_part * 4) * 4u : 0x80000000u;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(win + (i * RPP * WW + wave_u * 8) * SLICE),
+                                                                     16, (int)vo, (int)so, 0, 0);
+                        }
+                        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (a few offsets at a time: the accumulators fill the file)
+                    }
+                }
+            } else {
                 const int gx = ox + my_col;
                 const bool xok = col_ok && (unsigned)gx < (unsigned)Wq;
                 const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
@@ -309,7 +335,7 @@ using GWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 using GQuad16 = TileCfg<16, 32, 6, 16, 6, 768>;
 using GQuad32 = TileCfg<32, 32, 6, 16, 6, 768>;
 
-template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1>
+template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1, bool DMA = false>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
                         SamplingLayout lay, int B, int S, int M, float *out, const int *local_hits)
@@ -317,15 +343,15 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
     // dynamic LDS: the larger of this kernel's window and the fallback body's
     constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
                                                                                    : TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
-    auto kernel = &msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT>;
+    auto kernel = &msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT>, Cfg::THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>, Cfg::THREADS,
                                                          LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
@@ -348,7 +374,7 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
     if (L >= 9 && L <= 16) {           // many cameras: 4 lane groups x up to 4 cameras (NG is the template's loop bound)
         switch ((D == 32 ? 100 : 0) + L) {
 #define QUAD_CASE(DD, LL, CFG)                                                                                       \
-        case DD + LL: return fused == 2 ? launch_group<CFG, LL, 3, 2, 4>(GROUP_ARGS) : fused ? launch_group<CFG, LL, 3, 1, 4>(GROUP_ARGS) \
+        case DD + LL: return fused == 2 ? launch_group<CFG, LL, 3, 2, 4, true>(GROUP_ARGS) : fused ? launch_group<CFG, LL, 3, 1, 4, true>(GROUP_ARGS) \
                                                                                         : launch_group<CFG, LL, 3, 0, 4>(GROUP_ARGS);
         QUAD_CASE(0, 9, GQuad16) QUAD_CASE(0, 10, GQuad16) QUAD_CASE(0, 11, GQuad16) QUAD_CASE(0, 12, GQuad16)
         QUAD_CASE(0, 13, GQuad16) QUAD_CASE(0, 14, GQuad16) QUAD_CASE(0, 15, GQuad16) QUAD_CASE(0, 16, GQuad16)
@@ -358,10 +384,12 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
         default: break;
         }
     }
-    if (D == 16 && L == 7) return fused == 2 ? launch_group<GWide16, 7, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide16, 7, 2, 1>(GROUP_ARGS) : launch_group<GWide16, 7, 2, 0>(GROUP_ARGS);
-    if (D == 16 && L == 6) return fused == 2 ? launch_group<GWide16, 6, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide16, 6, 2, 1>(GROUP_ARGS) : launch_group<GWide16, 6, 2, 0>(GROUP_ARGS);
-    if (D == 32 && L == 7) return fused == 2 ? launch_group<GWide32, 7, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide32, 7, 2, 1>(GROUP_ARGS) : launch_group<GWide32, 7, 2, 0>(GROUP_ARGS);
-    if (D == 32 && L == 6) return fused == 2 ? launch_group<GWide32, 6, 2, 2>(GROUP_ARGS) : fused ? launch_group<GWide32, 6, 2, 1>(GROUP_ARGS) : launch_group<GWide32, 6, 2, 0>(GROUP_ARGS);
+    // fused entries copy their windows with LDS-DMA (measured at Wildtrack size: 136 -> 127 us; the public contract's
+    // kernel is a shade slower with it, 172 -> 174 us, and keeps the register-staged copy)
+    if (D == 16 && L == 7) return fused == 2 ? launch_group<GWide16, 7, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide16, 7, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide16, 7, 2, 0>(GROUP_ARGS);
+    if (D == 16 && L == 6) return fused == 2 ? launch_group<GWide16, 6, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide16, 6, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide16, 6, 2, 0>(GROUP_ARGS);
+    if (D == 32 && L == 7) return fused == 2 ? launch_group<GWide32, 7, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide32, 7, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide32, 7, 2, 0>(GROUP_ARGS);
+    if (D == 32 && L == 6) return fused == 2 ? launch_group<GWide32, 6, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide32, 6, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide32, 6, 2, 0>(GROUP_ARGS);
     return (int)hipErrorInvalidValue;
 }
 

@@ -515,7 +515,9 @@ static int launch_quad(hipStream_t st, const float *value, const int64_t *shapes
 
 bool msda_quad_supported(int M, int D, int L)
 {
-    static const bool enabled = [] { const char *e = getenv("MVDETR_MSDA_QUAD"); return !(e && e[0] == '0'); }();
+    // opt-in (MVDETR_MSDA_QUAD=1): measured 3 % ahead of the group kernel on the public contract and 12 % behind it on the
+    // fused one at Wildtrack size
+    static const bool enabled = [] { const char *e = getenv("MVDETR_MSDA_QUAD"); return e && e[0] == '1'; }();
     return enabled && ((D == 16 && M % 2 == 0) || D == 32) && L >= 2 && L <= 8;
 }
 
