@@ -17,8 +17,9 @@ Prints ONE JSON line (rank 0):
                    `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes
                    (profiles/*_traffic.json), null when that file is absent
   cpu_baseline     the oracle (the reference's CPU formulation: grid_sample-based deformable
-                   attention + kornia-semantics warp + the same trunk) timed on this box's host cores
-                   for a bounded number of frames; baseline only
+                   attention + kornia-semantics warp + the same trunk) timed on this box's host cores:
+                   a thread sweep (1, physical/2, physical) over the two hot ops on a bounded sample
+                   (2 warm-ups, median of 3), then whole frames at the best thread count; baseline only
   hot_path         the same step without trunk and heads (warp + shadow transformer), for scale
 
 Multi-GPU: `--parallel dp` (default) runs one independent frame per rank -- frames shard with no
@@ -62,7 +63,47 @@ def parse():
                     help="keep hipBLASLt's default solution per GEMM instead of PyTorch TunableOp's measured pick")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--msda-impl", default="auto", choices=["auto", "gather", "tile"])
+    ap.add_argument("--offset-std-px", type=float, default=1.0,
+                    help="std of the seeded perturbation of the learned sampling offsets, in pixels (SURVEY 8d: bias grid + "
+                         "N(0, 1 px)); 0 keeps the reference's zero-initialised projections (every query samples one constant pattern)")
     return ap.parse_args()
+
+
+def relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU,
+    the driver's own command shape) and hand back their exit code.  With fewer GPUs than ranks (a 1-GPU test box) the
+    ranks share GPUs and exchange through gloo, which stages CUDA tensors through the host -- RCCL wants one GPU per rank."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < a.gpus:
+        env.setdefault("MVDETR_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def perturb_sampling(model, std_px, seed=1234):
+    """Seeded stand-in for LEARNED sampling offsets / attention logits.  The reference initialises both projections'
+    weights to zero (ms_deform_attn.py:62-73), so with random-init weights every query would sample the same constant
+    1..4 px pattern -- the most local input there is.  SURVEY 8d defines the measurement input as bias grid +
+    N(0, 1 px): scale the offset projection so that its output has that spread on the model's own tokens."""
+    if std_px <= 0 or not hasattr(model.world_feat, "encoder"):
+        return None
+    g = torch.Generator().manual_seed(seed)
+    for layer in model.world_feat.encoder.layers:
+        at = layer.self_attn
+        with torch.no_grad():
+            # queries are LayerNorm outputs + position/camera embeddings: per-channel rms ~ 1.4 => std(w . q) ~ 1.4 * sqrt(C) * std(w)
+            at.sampling_offsets.weight.copy_(torch.randn(at.sampling_offsets.weight.shape, generator=g)
+                                             * (std_px / (1.4 * at.d_model ** 0.5)))
+            at.attention_weights.weight.copy_(torch.randn(at.attention_weights.weight.shape, generator=g)
+                                              * (1.0 / (1.4 * at.d_model ** 0.5)))
+    return std_px
 
 
 class KernelTimer:
@@ -113,56 +154,73 @@ def load_traffic():
         return None, None
 
 
+def _median_time(fn, warmup=2, reps=3):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
 def cpu_baseline(model, imgs_cpu, proj_cpu, budget_s):
-    """Full frame on the host through the oracle (reference CPU formulation), bounded wall time."""
-    from oracle import frame_oracle
+    """The oracle on the host.  (1) thread sweep over the two hot ops on a bounded sample -- MSDA core for ONE camera's
+    queries against all cameras' values, warp of ONE view -- 2 warm-ups + median of 3 at 1, physical/2 and physical
+    cores (all logical CPUs oversubscribe the oracle's OpenMP/oneDNN loops: 256 threads were slower than 1 on the
+    r01 box); (2) whole frames at the best thread count, bounded by `budget_s`."""
+    from helpers import encoder_msda_inputs
+    from oracle import frame_oracle, torch_oracle
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        import psutil
+        physical = min(logical, psutil.cpu_count(logical=False) or logical)
+    except Exception:
+        physical = max(1, logical // 2)
+    wf = model.world_feat
+    N = model.num_cam
+    h, w = (int(x) for x in wf.spatial_shapes[0])
+    value, shapes, _, loc, aw = encoder_msda_inputs(N, h, w, 8, wf.hidden_dim // 8, 4, seed=0)
+    one = slice(0, h * w)                                   # one camera's queries
+    loc1, aw1 = loc[:, one].contiguous(), aw[:, one].contiguous()
+    feat1 = torch.randn(1, wf.hidden_dim, *model.Rimg_shape)
+    sweep = {}
+    for nt in sorted({1, max(1, physical // 2), physical}):
+        torch.set_num_threads(nt)
+        with torch.no_grad():
+            t_msda = _median_time(lambda: torch_oracle.msda_core(value, shapes, loc1, aw1))
+            t_warp = _median_time(lambda: torch_oracle.warp_perspective(feat1, proj_cpu[:1], model.Rworld_shape))
+        sweep[nt] = {"msda_core_one_camera_s": round(t_msda, 4), "warp_one_view_s": round(t_warp, 4)}
+    best = min(sweep, key=lambda k: sweep[k]["msda_core_one_camera_s"] * N + sweep[k]["warp_one_view_s"] * N)
+    torch.set_num_threads(best)
     p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref = model.world_feat.encoder.reference_points.detach().cpu()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    def one():
+
+    def frame():
         t0 = time.perf_counter()
         with torch.no_grad():
             frame_oracle.forward(p, imgs_cpu, proj_cpu, model.Rworld_shape, ref, model.num_cam)
         return time.perf_counter() - t0
 
-    first = one()
-    times = [first]
-    if first < budget_s / 3:                    # cheap enough: treat the first call as warm-up
+    times = [frame()]                                       # warm-up, kept only if there is no time for more
+    if times[0] < budget_s / 3:
         times = []
-        while len(times) < 5 and sum(times) + first <= budget_s:
-            times.append(one())
-    frames, t_total = len(times), sum(times)
-    res = {"value": round(frames / t_total, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-           "sample": f"{frames} full frame(s) ({model.num_cam} views 3x{imgs_cpu.shape[-2]}x{imgs_cpu.shape[-1]} -> BEV), "
-                     f"oracle/frame_oracle.py on {torch.get_num_threads()} host threads, {t_total:.1f} s"}
-    # the two hot ops alone (the reference's CPU formulation), all cores and -- because the reference pins
-    # OMP_NUM_THREADS=1 (main.py:3) -- one thread; one call each, a few seconds in total
-    from helpers import encoder_msda_inputs
-    from oracle import torch_oracle
-    wf = model.world_feat
-    h, w = (int(x) for x in wf.spatial_shapes[0])
-    value, shapes, _, loc, aw = encoder_msda_inputs(model.num_cam, h, w, 8, wf.hidden_dim // 8, 4, seed=0)
-    feat = torch.randn(model.num_cam, wf.hidden_dim, *model.Rimg_shape)
-    ops = {}
-    with torch.no_grad():
-        torch_oracle.msda_core(value, shapes, loc, aw)          # warm-up (allocator, thread pool)
-    for tag, nthreads in (("all_cores", cores), ("1_thread", 1)):
-        torch.set_num_threads(nthreads)
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            torch_oracle.msda_core(value, shapes, loc, aw)
-            t1 = time.perf_counter()
-            torch_oracle.warp_perspective(feat, proj_cpu, model.Rworld_shape)
-            t2 = time.perf_counter()
-        ops[tag] = {"threads": nthreads, "msda_core_s": round(t1 - t0, 3), "warp_s": round(t2 - t1, 3)}
-    torch.set_num_threads(cores)
-    res["ops"] = ops
-    return res
+        while len(times) < 3 and sum(times) + (times[-1] if times else 0) <= budget_s:
+            times.append(frame())
+        times = times or [frame()]
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": f"median of {len(times)} whole frame(s) ({model.num_cam} views 3x{imgs_cpu.shape[-2]}x{imgs_cpu.shape[-1]} -> BEV) "
+                      f"through oracle/frame_oracle.py on {best} thread(s) after a warm-up frame, {sum(times):.1f} s; thread count chosen by the "
+                      f"sweep below (hot ops on one camera's share, 2 warm-ups + median of 3)",
+            "host": {"logical_cpus": logical, "physical_cores": physical}, "thread_sweep": {str(k): v for k, v in sweep.items()}}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(a))
     from mvdetr_amd import dist as mdist
     rank, world, local_rank = mdist.init_from_env()
     if not torch.cuda.is_available():
@@ -170,17 +228,26 @@ def main():
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     torch.backends.cudnn.benchmark = True      # the reference's own setting (main.py:48): MIOpen picks convolutions by measurement
+    gemm_tuning = False
     if not a.no_gemm_tuning:
         # the same for the shadow transformer's fp32 GEMMs: TunableOp times the hipBLASLt / rocBLAS solutions of each
-        # shape once (during the warm-up steps) and keeps the fastest; same arithmetic type, nothing is written to disk
+        # shape once (during the warm-up steps) and keeps the fastest; same arithmetic type, nothing is written to disk.
+        # All-or-nothing: if any step of the set-up fails, tuning is switched off again and the line says so.
         try:
             import tempfile
-            torch.cuda.tunable.enable(True)
-            torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_{os.getpid()}.csv"))
-            torch.cuda.tunable.write_file_on_exit(False)
-            torch.cuda.tunable.set_max_tuning_duration(200)
+            tun = torch.cuda.tunable
+            tun.set_filename(os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_{os.getpid()}.csv"))
+            tun.write_file_on_exit(False)
+            tun.set_max_tuning_duration(200)
+            tun.enable(True)
+            tun.tuning_enable(True)
+            gemm_tuning = bool(tun.is_enabled())
         except Exception as ex:                    # pragma: no cover
-            print(f"[bench] TunableOp unavailable: {ex}", file=sys.stderr)
+            try:
+                torch.cuda.tunable.enable(False)
+            except Exception:
+                pass
+            print(f"[bench] TunableOp unavailable, GEMMs keep the library defaults: {ex}", file=sys.stderr)
 
     import mvdetr_amd.ops  # noqa: F401
     import MultiScaleDeformableAttention as MSDA
@@ -191,7 +258,12 @@ def main():
     timer = KernelTimer(MSDA)      # callers look the functions up on the module at call time
 
     geom = geometry.GEOMETRIES[a.config]
-    model = build_model(a.config, seed=0).to(dev).eval()
+    model = build_model(a.config, seed=0)
+    offset_std = perturb_sampling(model, a.offset_std_px)
+    model = model.to(dev).eval()
+    attn_layers = [layer.self_attn for layer in model.world_feat.encoder.layers] if hasattr(model.world_feat, "encoder") else []
+    for at in attn_layers:
+        at.cache_fused_projection(True)                     # inference with frozen weights (see MSDeformAttn)
     N, (Hi, Wi) = geom.num_cam, geom.input_img_shape
     g = torch.Generator().manual_seed(1000 + rank)
     Bf = a.batch if not (a.parallel == "views" and world > 1) else 1
@@ -226,7 +298,12 @@ def main():
     elapsed = mdist.barrier_and_max(time.perf_counter() - t0, dev)
     timer.enabled = False
     k_us, k_n, k_bytes = timer.average_us()
-    impl = MSDA.last_forward_impl()
+    impl = MSDA.last_forward_kernel()
+    # ranks the collective library actually connected (one process may be all there is)
+    seen = torch.ones(1, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(seen)
+    n_ranks = int(seen.item())
 
     # ---- the hot path alone (warp + shadow transformer), same inputs ------------------------------------
     hot_ms = None
@@ -243,6 +320,30 @@ def main():
             torch.cuda.synchronize()
             hot_ms = (time.perf_counter() - t1) / a.steps * 1e3 / Bf
 
+    # ---- the same kernel on the reference's initial (zero) offset / attention weights, for comparison ---------------
+    init_us = None
+    if a.parallel == "dp" and offset_std and attn_layers:
+        saved = [(at.sampling_offsets.weight.detach().clone(), at.attention_weights.weight.detach().clone()) for at in attn_layers]
+        with torch.no_grad():
+            for at in attn_layers:
+                at.sampling_offsets.weight.zero_()
+                at.attention_weights.weight.zero_()
+                at.cache_fused_projection(True)
+            model.hot_path(feat, proj)
+            n0 = len(timer.events)
+            timer.enabled = True
+            for _ in range(5):
+                model.hot_path(feat, proj)
+            torch.cuda.synchronize()
+            timer.enabled = False
+            ts = [e0.elapsed_time(e1) * 1e3 for e0, e1, _ in timer.events[n0:]]
+            init_us = sum(ts) / len(ts)
+            del timer.events[n0:]
+            for at, (ow, aw) in zip(attn_layers, saved):
+                at.sampling_offsets.weight.copy_(ow)
+                at.attention_weights.weight.copy_(aw)
+                at.cache_fused_projection(True)
+
     if rank != 0:
         return
     alg_bytes = int(k_bytes) if k_bytes else None          # of the launches actually timed (rank 0's)
@@ -252,19 +353,27 @@ def main():
     res = {
         "metric": "multiview frames/s (7-cam Wildtrack) + MSDeformAttn HBM GB/s vs roofline",
         "value": round(frames_per_step * a.steps / elapsed, 3), "unit": "frames/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "n_gpus": n_ranks, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{a.config} {N}-cam frame, --world_feat deform_trans, ResNet18 trunk: "
                                f"{N}x3x{Hi}x{Wi} -> {geom.feat_channels}-ch world feat {geom.Rworld_shape[0]}x{geom.Rworld_shape[1]} "
                                f"-> BEV (BASELINE.json configs[1])" if a.config == "wildtrack" else f"{a.config} {N}-cam frame",
                    "frames_per_step": frames_per_step, "batch_per_rank": Bf, "parallelism": f"{a.parallel}{world}" + (f"-{a.encoder}" if a.parallel == "views" and world > 1 else ""),
-                   "augment": bool(a.augment), "gemm_tuning": not a.no_gemm_tuning,
-                   "weights": "seeded random"},
-        "roofline": {"bound": "hbm", "kernel": f"msda_forward[{impl}]", "achieved": round(achieved, 1) if achieved else None,
+                   "augment": bool(a.augment), "gemm_tuning": gemm_tuning,
+                   "backend": (os.environ.get("MVDETR_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else None,
+                   "gpus_visible": torch.cuda.device_count(),
+                   "weights": "seeded random" + (f"; sampling-offset / attention projections perturbed (seeded) to ~{offset_std:g} px offset std, "
+                                                 "SURVEY 8d's locality-realistic input" if offset_std else "; reference init (zero offset weights)")},
+        "roofline": {"bound": "hbm", "kernel": impl, "achieved": round(achieved, 1) if achieved else None,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4) if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                     "avg_launch_us": round(k_us, 2) if k_us else None, "launches_timed": k_n},
+                     "avg_launch_us": round(k_us, 2) if k_us else None, "launches_timed": k_n,
+                     "input": (f"learned-like offsets: bias grid + ~N(0, {offset_std:g} px) (SURVEY 8d)" if offset_std
+                               else "reference init: constant bias-grid offsets"),
+                     "init_weights": ({"avg_launch_us": round(init_us, 2), "frac": round(alg_bytes / (init_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                                       "what": "same kernel, zero offset / attention weights (every query samples the constant bias grid)"}
+                                      if (init_us and alg_bytes) else None)},
         "hot_path": {"ms_per_frame": round(hot_ms, 3) if hot_ms else None,
                      "frames_per_s": round(1e3 / hot_ms, 1) if hot_ms else None,
                      "what": "warp_perspective + DeformTransWorldFeat (3 x MSDeformAttn), features resident"},

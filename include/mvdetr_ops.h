@@ -131,7 +131,7 @@ int mvdetr_msda_backward_f64(void *stream, const double *grad_col, const double 
  *   src  [n, channels, src_h, src_w]        (NCHW, like the reference's imgs_feat)
  *   M    [n, 3, 3]  destination pixel <- source pixel homography, same dtype as src
  *   dst  [n, channels, dst_h, dst_w]        every element is written (zeros outside the view)
- * `layout_nhwc` is a bit mask.  Bit 0 (value 1): dst is written as [n, dst_h, dst_w, channels] instead (the
+ * `layout_nhwc` is a bit mask (bit 2, value 4: mode='nearest' instead of bilinear -- frameDataset.py:80).  Bit 0 (value 1): dst is written as [n, dst_h, dst_w, channels] instead (the
  * token layout the shadow transformer consumes, trans_world_feat.py:92), saving the permute copy.  Bit 1
  * (value 2): src is [n, src_h, src_w, channels] -- what a channels_last trunk produces -- so every bilinear
  * corner is one contiguous channel vector; supported together with bit 0 (value 3), channels a multiple of
@@ -177,12 +177,43 @@ int mvdetr_add_layernorm_add_f32(void *stream, const float *x, const float *resi
  * Name of the kernel variant the last forward call ON THIS THREAD dispatched to
  * ("gather", "tile16", ...).  Static storage; never NULL. */
 const char *mvdetr_msda_last_forward_impl(void);
+/* Name of the kernel that call launched ("msda_fwd_group[LDS-DMA windows]", "msda_fwd_tile", "msda_fwd_gather", ...). */
+const char *mvdetr_msda_last_forward_kernel(void);
 
 /* Forward kernel variant selection: 0 = auto (default; tiled LDS kernel where it applies, else
  * the gather kernel), 1 = always gather, 2 = tile whenever the shape supports it.  Results are
  * identical up to fp32 summation order; this is a tuning/testing knob.  Returns the previous value.
  * Initial value comes from MVDETR_MSDA_FWD_IMPL = auto | gather | tile. */
 int mvdetr_msda_set_forward_impl(int impl);
+
+/* ---- CPU path (host pointers, no stream, synchronous) ------------------------------------------------------------
+ * The reference extension raises for CPU tensors (ms_deform_attn_cpu.cpp:17-41 are stubs; ms_deform_attn.h:38,60).
+ * These entry points make the same contracts work on host memory: same argument meaning and layouts as the device
+ * functions above; std::thread parallel (MVDETR_HOST_THREADS, else OMP_NUM_THREADS, else all cores up to 64);
+ * deterministic (no atomics).  grad_value / grad_src are ACCUMULATED into: pass them zeroed.
+ * warp: `layout_nhwc` bits 0/1 as above; `mode` 0 = bilinear, 1 = nearest.  Return 0 on success. */
+int mvdetr_msda_forward_host_f32(const float *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                 const float *sampling_loc, const float *attn_weight, int batch, int spatial_size,
+                                 int num_heads, int channels, int num_levels, int num_query, int num_point, float *out);
+int mvdetr_msda_forward_host_f64(const double *value, const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                 const double *sampling_loc, const double *attn_weight, int batch, int spatial_size,
+                                 int num_heads, int channels, int num_levels, int num_query, int num_point, double *out);
+int mvdetr_msda_backward_host_f32(const float *grad_output, const float *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start_index, const float *sampling_loc, const float *attn_weight,
+                                  int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                  int num_point, float *grad_value, float *grad_sampling_loc, float *grad_attn_weight);
+int mvdetr_msda_backward_host_f64(const double *grad_output, const double *value, const int64_t *spatial_shapes,
+                                  const int64_t *level_start_index, const double *sampling_loc, const double *attn_weight,
+                                  int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                  int num_point, double *grad_value, double *grad_sampling_loc, double *grad_attn_weight);
+int mvdetr_warp_perspective_forward_host_f32(const float *src, const float *mats, int n, int channels, int src_h, int src_w,
+                                             int dst_h, int dst_w, int layout_nhwc, int mode, float *dst);
+int mvdetr_warp_perspective_forward_host_f64(const double *src, const double *mats, int n, int channels, int src_h, int src_w,
+                                             int dst_h, int dst_w, int layout_nhwc, int mode, double *dst);
+int mvdetr_warp_perspective_backward_host_f32(const float *grad_dst, const float *mats, int n, int channels, int src_h,
+                                              int src_w, int dst_h, int dst_w, int layout_nhwc, int mode, float *grad_src);
+int mvdetr_warp_perspective_backward_host_f64(const double *grad_dst, const double *mats, int n, int channels, int src_h,
+                                              int src_w, int dst_h, int dst_w, int layout_nhwc, int mode, double *grad_src);
 
 #ifdef __cplusplus
 }

@@ -21,12 +21,16 @@ _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
 _MSDA_BWD = [_vp] * 7 + [_i] * 7 + [_vp] * 3
 _WARP = [_vp] * 3 + [_i] * 7 + [_vp]
+_MSDA_FWD_HOST = [_vp] * 5 + [_i] * 7 + [_vp]
+_MSDA_BWD_HOST = [_vp] * 6 + [_i] * 7 + [_vp] * 3
+_WARP_HOST = [_vp] * 2 + [_i] * 8 + [_vp]
 _MSDA_FUSED = [_vp] * 5 + [ctypes.c_int64] + [_vp] * 2 + [_i] * 10 + [_vp]
 _MSDA_FUSED_LEVELS = [_vp] * 5 + [ctypes.c_int64] + [_vp] * 2 + [_i] * 12 + [_vp]
 
 SIGNATURES = {
     "mvdetr_ops_abi_version": ([], _i),
     "mvdetr_msda_last_forward_impl": ([], ctypes.c_char_p),
+    "mvdetr_msda_last_forward_kernel": ([], ctypes.c_char_p),
     "mvdetr_msda_set_forward_impl": ([_i], _i),
     "mvdetr_msda_forward_f32": (_MSDA_FWD, _i),
     "mvdetr_msda_forward_f64": (_MSDA_FWD, _i),
@@ -42,6 +46,14 @@ SIGNATURES = {
     "mvdetr_warp_perspective_forward_f64": (_WARP, _i),
     "mvdetr_warp_perspective_backward_f32": (_WARP, _i),
     "mvdetr_warp_perspective_backward_f64": (_WARP, _i),
+    "mvdetr_msda_forward_host_f32": (_MSDA_FWD_HOST, _i),
+    "mvdetr_msda_forward_host_f64": (_MSDA_FWD_HOST, _i),
+    "mvdetr_msda_backward_host_f32": (_MSDA_BWD_HOST, _i),
+    "mvdetr_msda_backward_host_f64": (_MSDA_BWD_HOST, _i),
+    "mvdetr_warp_perspective_forward_host_f32": (_WARP_HOST, _i),
+    "mvdetr_warp_perspective_forward_host_f64": (_WARP_HOST, _i),
+    "mvdetr_warp_perspective_backward_host_f32": (_WARP_HOST, _i),
+    "mvdetr_warp_perspective_backward_host_f64": (_WARP_HOST, _i),
 }
 
 

@@ -7,6 +7,9 @@ namespace mvdetr {
 
 enum class MsdaFwdImpl { Gather, Tile };
 
+// name of the kernel the last forward on this thread launched (bench / tests only; set by the launchers)
+void msda_note_forward_kernel(const char *name);
+
 // fp32 LDS-tiled encoder kernel (msda_forward_tile.hip).  Only valid when
 // msda_fwd_choose_impl() returned Tile.
 // local_hits: device counter written by msda_launch_locality_probe (or NULL: no probe)

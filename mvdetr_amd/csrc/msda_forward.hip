@@ -95,6 +95,8 @@ template int msda_forward_gather<double>(hipStream_t, const double *, const int6
                                          int, double *);
 
 static thread_local const char *g_last_impl = "none";
+static thread_local const char *g_last_kernel = "none";
+void msda_note_forward_kernel(const char *name) { g_last_kernel = name; }
 
 static bool bad_dims(int B, int S, int M, int D, int L, int Lq, int P)
 {
@@ -130,6 +132,7 @@ static int forward_entry(void *stream, const T *value, const int64_t *shapes, co
         }
     }
     g_last_impl = "gather";
+    g_last_kernel = "msda_fwd_gather";
     return msda_forward_gather<T>(st, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out);
 }
 
@@ -140,6 +143,7 @@ extern "C" {
 int mvdetr_ops_abi_version(void) { return MVDETR_OPS_ABI_VERSION; }
 
 const char *mvdetr_msda_last_forward_impl(void) { return mvdetr::g_last_impl; }
+const char *mvdetr_msda_last_forward_kernel(void) { return mvdetr::g_last_kernel; }
 
 int mvdetr_msda_set_forward_impl(int impl)
 {

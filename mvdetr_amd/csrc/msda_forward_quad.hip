@@ -508,6 +508,7 @@ static int launch_quad(hipStream_t st, const float *value, const int64_t *shapes
             cus = 256;
         return (cus + 7) / 8 * 8;                          // one workgroup per CU (2 x 64.5 KB of LDS each)
     }();
+    msda_note_forward_kernel("msda_fwd_quad");
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(quad::THREADS), quad::LDS_BYTES, st, value, shapes, lsi, off,
                        logit, ref, ref_bstride, lay, B, S, M, out, local_hits);
     return (int)hipGetLastError();

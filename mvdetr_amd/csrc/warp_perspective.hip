@@ -56,9 +56,16 @@ __device__ __forceinline__ void source_position(const T *__restrict__ Mn, int i,
     y = ((qy * s + 1.0) * (double)h - 1.0) * 0.5;
 }
 
-__device__ __forceinline__ SrcCoord make_coord(double x, double y, int h, int w)
+// nearest: grid_sample(mode='nearest') rounds the position half-to-even and takes that texel; here it becomes a
+// bilinear footprint whose first corner carries all the weight (the call kornia.warp_perspective(..., 'nearest') of
+// frameDataset.py:80)
+__device__ __forceinline__ SrcCoord make_coord(double x, double y, int h, int w, int nearest)
 {
     SrcCoord c;
+    if (nearest) {
+        x = rint(x);
+        y = rint(y);
+    }
     // reject far-out / non-finite positions before the int conversion
     const bool in = x > -1.0 && y > -1.0 && x < (double)w && y < (double)h;
     const double fx = floor(x), fy = floor(y);
@@ -70,9 +77,9 @@ __device__ __forceinline__ SrcCoord make_coord(double x, double y, int h, int w)
     c.wy0 = 1.0 - c.wy1;
     const bool vx0 = c.x0 >= 0, vx1 = c.x0 + 1 < w, vy0 = c.y0 >= 0, vy1 = c.y0 + 1 < h;
     c.v00 = in && vy0 && vx0;
-    c.v01 = in && vy0 && vx1;
-    c.v10 = in && vy1 && vx0;
-    c.v11 = in && vy1 && vx1;
+    c.v01 = in && vy0 && vx1 && !nearest;
+    c.v10 = in && vy1 && vx0 && !nearest;
+    c.v11 = in && vy1 && vx1 && !nearest;
     c.any = c.v00 || c.v01 || c.v10 || c.v11;
     return c;
 }
@@ -129,7 +136,7 @@ inline int64_t warp_grid(int N, int H, int W, int groups)
 template <typename T, bool NHWC>
 __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
     const T *__restrict__ src, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
-    T *__restrict__ dst)
+    int nearest, T *__restrict__ dst)
 {
     __shared__ float tile[NHWC && sizeof(T) == 4 ? WARP_PIX * (WARP_CH + 1) : 1];
     const int lane = threadIdx.x & (WARP_PIX - 1);
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
     if (live) {
         double x, y;
         source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
-        sc = make_coord(x, y, h, w);
+        sc = make_coord(x, y, h, w, nearest);
     }
     const T w00 = T(sc.wy0 * sc.wx0), w01 = T(sc.wy0 * sc.wx1);
     const T w10 = T(sc.wy1 * sc.wx0), w11 = T(sc.wy1 * sc.wx1);
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
 template <typename T, bool NHWC>
 __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_bwd(
     const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
-    T *__restrict__ grad_src)
+    int nearest, T *__restrict__ grad_src)
 {
     const int lane = threadIdx.x & (WARP_PIX - 1);
     const int sub = threadIdx.x / WARP_PIX;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_bwd(
     constexpr int CPT = WARP_CH / WARP_SUB;
     double x, y;
     source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
-    const SrcCoord sc = make_coord(x, y, h, w);
+    const SrcCoord sc = make_coord(x, y, h, w, nearest);
     if (!sc.any) return;
     const T w00 = T(sc.wy0 * sc.wx0), w01 = T(sc.wy0 * sc.wx1);
     const T w10 = T(sc.wy1 * sc.wx0), w11 = T(sc.wy1 * sc.wx1);
@@ -234,7 +241,7 @@ template <typename T> struct WarpTexel {
 };
 
 template <typename T>
-__device__ __forceinline__ WarpTexel<T> warp_texel(const T *__restrict__ Mn, int i, int j, int h, int w, bool live)
+__device__ __forceinline__ WarpTexel<T> warp_texel(const T *__restrict__ Mn, int i, int j, int h, int w, bool live, int nearest)
 {
     WarpTexel<T> t;
     t.o00 = 0;
@@ -243,7 +250,7 @@ __device__ __forceinline__ WarpTexel<T> warp_texel(const T *__restrict__ Mn, int
     if (live) {
         double x, y;
         source_position(Mn, i, j, h, w, x, y);
-        const SrcCoord sc = make_coord(x, y, h, w);
+        const SrcCoord sc = make_coord(x, y, h, w, nearest);
         t.o00 = sc.y0 * w + sc.x0;
         t.w00 = T(sc.wy0 * sc.wx0);
         t.w01 = T(sc.wy0 * sc.wx1);
@@ -259,7 +266,7 @@ constexpr int WARP_CL_THREADS = 256;
 template <typename T>
 __global__ __launch_bounds__(WARP_CL_THREADS) void warp_fwd_cl(
     const T *__restrict__ src, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
-    T *__restrict__ dst)
+    int nearest, T *__restrict__ dst)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ WarpTexel<T> tex[WARP_PIX];
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_fwd_cl(
     const int n = wb.n;
     if (threadIdx.x < WARP_PIX) {
         const int i = wb.i0 + threadIdx.x / WARP_TW, j = wb.j0 + threadIdx.x % WARP_TW;
-        tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W);
+        tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W, nearest);
     }
     __syncthreads();
     const int chunks = C / VEC;                                   // 16-byte chunks per pixel
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_fwd_cl(
 template <typename T>
 __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
     const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
-    T *__restrict__ grad_src)
+    int nearest, T *__restrict__ grad_src)
 {
     __shared__ WarpTexel<T> tex[WARP_PIX];
     WarpBlock wb;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
     const int n = wb.n;
     if (threadIdx.x < WARP_PIX) {
         const int i = wb.i0 + threadIdx.x / WARP_TW, j = wb.j0 + threadIdx.x % WARP_TW;
-        tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W);
+        tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W, nearest);
     }
     __syncthreads();
     T *view = grad_src + (int64_t)n * h * w * C;
@@ -338,7 +345,9 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
     if (npix == 0 || C == 0) return 0;
     if (!a || !Mv || !o) return (int)hipErrorInvalidValue;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (nhwc & ~3) return (int)hipErrorInvalidValue;
+    if (nhwc & ~7) return (int)hipErrorInvalidValue;
+    const int nearest = (nhwc >> 2) & 1;                   // bit 2: mode='nearest'
+    nhwc &= 3;
     if (nhwc & 2) {
         // channel-last source: implemented for channel-last destinations, whole 16-byte chunks per pixel and a
         // view that fits 32-bit element offsets
@@ -348,9 +357,9 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
         const int64_t nb = warp_grid(N, H, W, 1);
         if (nb > 0x7fffffffLL) return (int)hipErrorInvalidValue;
         if (!backward)
-            hipLaunchKernelGGL((warp_fwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, o);
+            hipLaunchKernelGGL((warp_fwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
         else
-            hipLaunchKernelGGL((warp_bwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, o);
+            hipLaunchKernelGGL((warp_bwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
         return (int)hipGetLastError();
     }
     const int groups = (C + WARP_CH - 1) / WARP_CH;
@@ -358,11 +367,11 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(WARP_PIX * WARP_SUB);
     if (!backward) {
-        if (nhwc) hipLaunchKernelGGL((warp_fwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
-        else hipLaunchKernelGGL((warp_fwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
+        if (nhwc) hipLaunchKernelGGL((warp_fwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+        else hipLaunchKernelGGL((warp_fwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
     } else {
-        if (nhwc) hipLaunchKernelGGL((warp_bwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
-        else hipLaunchKernelGGL((warp_bwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, o);
+        if (nhwc) hipLaunchKernelGGL((warp_bwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+        else hipLaunchKernelGGL((warp_bwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
     }
     return (int)hipGetLastError();
 }

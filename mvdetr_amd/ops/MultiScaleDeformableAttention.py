@@ -9,7 +9,10 @@ Differences from the reference, all deliberate:
   * kernel launch failures raise RuntimeError instead of being printf'd (cuh:948-952);
   * the batch is not chunked by im2col_step -- the kernels take the whole batch in one launch --
     but the divisibility check (cu:52) is kept so the same misuse raises the same way;
-  * forward output is allocated with empty() (the kernel writes every element) instead of zeros().
+  * forward output is allocated with empty() (the kernel writes every element) instead of zeros();
+  * CPU tensors WORK: the reference raises "Not implemented on the CPU" (ms_deform_attn.h:38,60 -- its
+    ms_deform_attn_cpu.cpp:17-41 are stubs); here they run on the library's own host implementation
+    (csrc/host_path.cpp, std::thread), same contract, deterministic.  All tensors of a call must live on one device.
 """
 from __future__ import annotations
 
@@ -18,15 +21,20 @@ import torch
 from .. import _lib
 
 
-def _check_inputs(named):
+def _check_inputs(named, allow_host=False):
+    """Contiguity and device checks of ms_deform_attn_cuda.cu:28-38.  Returns True when the call is a host call (every
+    tensor on the CPU; only where ``allow_host``), False for a device call; mixed devices raise."""
     for name, t in named:
         if not t.is_contiguous():
             raise RuntimeError(f"{name} tensor has to be contiguous")
+    if allow_host and not any(t.is_cuda for _, t in named):
+        return True
     for name, t in named:
         if not t.is_cuda:
             # ms_deform_attn.h:38,60
-            raise RuntimeError("Not implemented on the CPU" if name == "value"
+            raise RuntimeError("Not implemented on the CPU" if name == "value" and not allow_host
                                else f"{name} must be a CUDA tensor")
+    return False
 
 
 def _dims(value, spatial_shapes, sampling_loc, im2col_step):
@@ -48,15 +56,21 @@ def _meta(t, device):
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                            im2col_step):
     """-> Tensor[batch, num_query, num_heads*channels]  (vision.cpp:14; ms_deform_attn_cuda.cu:20-80)"""
-    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
-                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
-                   ("attn_weight", attn_weight)])
+    host = _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                          ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                          ("attn_weight", attn_weight)], allow_host=True)
     B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
     sfx = _lib.suffix(value.dtype)
     if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
         raise RuntimeError("value, sampling_loc and attn_weight must have the same dtype")
     _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)
     out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    if host:
+        rc = getattr(_lib.lib(), f"mvdetr_msda_forward_host_{sfx}")(
+            value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_loc.data_ptr(),
+            attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr())
+        _lib.check(rc, "ms_deform_attn_forward (host)")
+        return out
     with torch.cuda.device(value.device):
         rc = getattr(_lib.lib(), f"mvdetr_msda_forward_{sfx}")(
             _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(),
@@ -69,9 +83,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                             grad_output, im2col_step):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]  (vision.cpp:15; cu:83-153)"""
-    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
-                   ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
-                   ("attn_weight", attn_weight), ("grad_output", grad_output)])
+    host = _check_inputs([("value", value), ("spatial_shapes", spatial_shapes),
+                          ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
+                          ("attn_weight", attn_weight), ("grad_output", grad_output)], allow_host=True)
     B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
     sfx = _lib.suffix(value.dtype)
     if any(t.dtype != value.dtype for t in (sampling_loc, attn_weight, grad_output)):
@@ -80,6 +94,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_value = torch.zeros_like(value)              # accumulated with atomics
     grad_loc = torch.empty_like(sampling_loc)         # fully written
     grad_aw = torch.empty_like(attn_weight)           # fully written
+    if host:
+        rc = getattr(_lib.lib(), f"mvdetr_msda_backward_host_{sfx}")(
+            grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P, grad_value.data_ptr(),
+            grad_loc.data_ptr(), grad_aw.data_ptr())
+        _lib.check(rc, "ms_deform_attn_backward (host)")
+        return [grad_value, grad_loc, grad_aw]
     with torch.cuda.device(value.device):
         rc = getattr(_lib.lib(), f"mvdetr_msda_backward_{sfx}")(
             _lib.current_stream_ptr(value.device), grad_output.data_ptr(), value.data_ptr(),
@@ -199,6 +220,11 @@ def slice_major_rows(M, L, P, D):
 def last_forward_impl() -> str:
     """Which kernel variant the last forward on this thread dispatched to (bench/tests only)."""
     return _lib.lib().mvdetr_msda_last_forward_impl().decode()
+
+
+def last_forward_kernel() -> str:
+    """Name of the kernel the last forward on this thread launched (bench/tests only)."""
+    return _lib.lib().mvdetr_msda_last_forward_kernel().decode()
 
 
 _IMPLS = {"auto": 0, "gather": 1, "tile": 2}

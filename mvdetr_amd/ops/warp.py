@@ -13,10 +13,16 @@ from torch.autograd.function import once_differentiable
 from .. import _lib
 
 
-DST_NHWC, SRC_NHWC = 1, 2          # bits of the C ABI's layout_nhwc argument (include/mvdetr_ops.h)
+DST_NHWC, SRC_NHWC, NEAREST = 1, 2, 4          # bits of the C ABI's layout_nhwc argument (include/mvdetr_ops.h)
 
 
 def _launch(name, a, M, n, c, h, w, H, W, layout, out):
+    if not a.is_cuda:
+        # the library's own CPU path (csrc/host_path.cpp): same layouts; the interpolation mode is its own argument
+        rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_{name}_host_{_lib.suffix(a.dtype)}")(
+            a.data_ptr(), M.data_ptr(), n, c, h, w, H, W, layout & 3, 1 if layout & NEAREST else 0, out.data_ptr())
+        _lib.check(rc, f"warp_perspective_{name} (host)")
+        return
     with torch.cuda.device(a.device):
         rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_{name}_{_lib.suffix(a.dtype)}")(
             _lib.current_stream_ptr(a.device), a.data_ptr(), M.data_ptr(), n, c, h, w, H, W, layout,
@@ -28,19 +34,19 @@ def _channel_last_source(src, channels_last_out):
     """True when ``src`` ([N,C,h,w] shape) already lies in memory as [N,h,w,C] and the channel-last kernel
     takes it: then the warp reads it in place instead of copying it to NCHW first."""
     n, c, h, w = src.shape
-    return (channels_last_out and c > 1 and h * w > 1 and src.is_contiguous(memory_format=torch.channels_last)
+    return (channels_last_out and src.is_cuda and c > 1 and h * w > 1 and src.is_contiguous(memory_format=torch.channels_last)
             and not src.is_contiguous() and (c * src.element_size()) % 16 == 0 and src.data_ptr() % 16 == 0)
 
 
 class WarpPerspectiveFunction(Function):
     @staticmethod
-    def forward(ctx, src, M, dsize, channels_last_out):
+    def forward(ctx, src, M, dsize, channels_last_out, nearest=False):
         n, c, h, w = src.shape
         H, W = int(dsize[0]), int(dsize[1])
         src_cl = _channel_last_source(src, channels_last_out)
         if not src_cl:
             src = src.contiguous()
-        layout = (DST_NHWC if channels_last_out else 0) | (SRC_NHWC if src_cl else 0)
+        layout = (DST_NHWC if channels_last_out else 0) | (SRC_NHWC if src_cl else 0) | (NEAREST if nearest else 0)
         shape = (n, H, W, c) if channels_last_out else (n, c, H, W)
         out = torch.empty(shape, dtype=src.dtype, device=src.device)
         _launch("forward", src, M, n, c, h, w, H, W, layout, out)
@@ -53,18 +59,19 @@ class WarpPerspectiveFunction(Function):
     def backward(ctx, grad_out):
         (M,) = ctx.saved_tensors
         n, c, h, w, H, W, layout = ctx.geom
-        if (c * grad_out.element_size()) % 16 == 0:
+        near = layout & NEAREST
+        if grad_out.is_cuda and (c * grad_out.element_size()) % 16 == 0:
             # channel-last on both sides whatever the forward's layouts were: the scatter is bound by atomic
             # REQUESTS, and with channels innermost a corner is one contiguous run (4.7 ms -> 0.39 ms at Wildtrack
             # size); NCHW gradients are transposed on the way in / out (a copy each, ~0.1 ms together)
             g = grad_out if layout & DST_NHWC else grad_out.permute(0, 2, 3, 1)
             grad_src = torch.empty((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device,
                                    memory_format=torch.channels_last).zero_()
-            _launch("backward", g.contiguous(), M, n, c, h, w, H, W, DST_NHWC | SRC_NHWC, grad_src)
-            return (grad_src if layout & SRC_NHWC else grad_src.contiguous()), None, None, None
+            _launch("backward", g.contiguous(), M, n, c, h, w, H, W, DST_NHWC | SRC_NHWC | near, grad_src)
+            return (grad_src if layout & SRC_NHWC else grad_src.contiguous()), None, None, None, None
         grad_src = torch.zeros((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device)
-        _launch("backward", grad_out.contiguous(), M, n, c, h, w, H, W, layout & DST_NHWC, grad_src)
-        return grad_src, None, None, None
+        _launch("backward", grad_out.contiguous(), M, n, c, h, w, H, W, (layout & DST_NHWC) | near, grad_src)
+        return grad_src, None, None, None, None
 
 
 def warp_perspective(src, M, dsize, mode="bilinear", padding_mode="zeros", align_corners=False,
@@ -77,17 +84,18 @@ def warp_perspective(src, M, dsize, mode="bilinear", padding_mode="zeros", align
     (no NCHW copy; every bilinear corner is then one contiguous channel vector).
 
     ``M`` may live on the CPU (mvdetr.py:194 moves it each call); it is copied to ``src``'s device.
-    Only the configuration MVDeTr's model uses is implemented natively: bilinear, zero padding,
-    align_corners=False.
+    Modes: 'bilinear' (the model, mvdetr.py:194) and 'nearest' (the dataset's ground-plane masks,
+    frameDataset.py:80); zero padding and align_corners=False only, the configuration the reference uses.
+    CPU tensors run on the library's own host implementation (the reference has none; kornia does).
     """
-    if mode != "bilinear" or padding_mode != "zeros" or align_corners not in (False, None):
+    if mode not in ("bilinear", "nearest") or padding_mode != "zeros" or align_corners not in (False, None):
         raise NotImplementedError(
-            "warp_perspective: only mode='bilinear', padding_mode='zeros', align_corners=False "
-            "(the MVDeTr model configuration) is implemented")
+            "warp_perspective: mode 'bilinear' or 'nearest', padding_mode='zeros', align_corners=False "
+            "(what MVDeTr calls) are implemented")
     if src.dim() != 4 or M.shape[-2:] != (3, 3) or M.reshape(-1, 3, 3).shape[0] != src.shape[0]:
         raise ValueError(f"warp_perspective: expected src [N,C,h,w] and M [N,3,3], got "
                          f"{tuple(src.shape)} and {tuple(M.shape)}")
-    if not src.is_cuda:
-        raise RuntimeError("warp_perspective: not implemented on the CPU (HIP extension only)")
+    if src.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("warp_perspective: float32 or float64 features")
     M = M.reshape(-1, 3, 3).to(device=src.device, dtype=src.dtype).contiguous()
-    return WarpPerspectiveFunction.apply(src, M, tuple(dsize), bool(channels_last_out))
+    return WarpPerspectiveFunction.apply(src, M, tuple(dsize), bool(channels_last_out), mode == "nearest")

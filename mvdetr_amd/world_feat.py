@@ -191,23 +191,33 @@ class DeformTransWorldFeat(nn.Module):
 
 
 class ConvWorldFeat(nn.Module):
-    """MVDet-style aggregation by dilated convolutions over the concatenated views + a coordinate
-    map (multiview_detector/models/conv_world_feat.py:21-52).  No MSDeformAttn involved; this is the
-    torch-only plumbing BASELINE.json's config 0 ('--world_feat conv') names."""
+    """MVDet-style aggregation: stride-2 conv per view, the views' channels concatenated with a 2-channel
+    coordinate map, three (dilated) 3x3 convolutions, bilinear upsampling back to the world grid and a 3x3 conv
+    (multiview_detector/models/conv_world_feat.py:21-52, same parameter names).  No MSDeformAttn involved; this is
+    the torch-only plumbing BASELINE.json's config 0 ('--world_feat conv') names.  Like the reference it needs
+    hidden_dim == base_dim (it views the down-sampled [B*N, hidden, h, w] as [B, N*base_dim, h, w], l.44); the
+    reference's reduction='sum' branch cannot run (it sums a 4-D tensor over its channel axis) and is not offered."""
 
     def __init__(self, num_cam, Rworld_shape, base_dim, hidden_dim=128, stride=2, reduction=None):
         super().__init__()
-        H, W = int(Rworld_shape[0]), int(Rworld_shape[1])
-        gx, gy = torch.meshgrid(torch.arange(W, dtype=torch.float32), torch.arange(H, dtype=torch.float32),
-                                indexing="xy")
-        coord = torch.stack([gx / (W - 1) * 2 - 1, gy / (H - 1) * 2 - 1], 0).unsqueeze(0)
+        if reduction is not None:
+            raise ValueError("only reduction=None exists (the reference's 'sum' branch is broken)")
+        if hidden_dim != base_dim:
+            raise ValueError("ConvWorldFeat needs hidden_dim == base_dim (conv_world_feat.py:44)")
+        H, W = int(Rworld_shape[0]) // stride, int(Rworld_shape[1]) // stride
+        self.downsample = nn.Sequential(nn.Conv2d(base_dim, hidden_dim, 3, stride, 1), nn.ReLU())
+        gx, gy = torch.meshgrid(torch.arange(W, dtype=torch.float64), torch.arange(H, dtype=torch.float64), indexing="xy")
+        coord = torch.stack([gx / (W - 1) * 2 - 1, gy / (H - 1) * 2 - 1], 0).unsqueeze(0).float()   # conv_world_feat.py:9-14
         self.register_buffer("coord_map", coord, persistent=False)
-        in_dim = base_dim * num_cam + 2
-        self.world_feat = nn.Sequential(nn.Conv2d(in_dim, hidden_dim, 3, padding=1), nn.ReLU(),
+        self.world_feat = nn.Sequential(nn.Conv2d(base_dim * num_cam + 2, hidden_dim, 3, padding=1), nn.ReLU(),
                                         nn.Conv2d(hidden_dim, hidden_dim, 3, padding=2, dilation=2), nn.ReLU(),
                                         nn.Conv2d(hidden_dim, hidden_dim, 3, padding=4, dilation=4), nn.ReLU())
+        self.upsample = nn.Sequential(nn.Upsample(list(map(int, Rworld_shape)), mode="bilinear", align_corners=False),
+                                      nn.Conv2d(hidden_dim, base_dim, 3, 1, 1), nn.ReLU())
 
     def forward(self, x, visualize=False):
         B, N, C, H, W = x.shape
-        x = torch.cat([x.reshape(B, N * C, H, W), self.coord_map.expand(B, -1, -1, -1)], 1)
-        return self.world_feat(x)
+        x = self.downsample(x.reshape(B * N, C, H, W))
+        h, w = x.shape[-2:]
+        x = torch.cat([x.reshape(B, N * C, h, w), self.coord_map.expand(B, -1, -1, -1)], 1)
+        return self.upsample(self.world_feat(x))

@@ -31,6 +31,7 @@ Parity status
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -195,3 +196,19 @@ def deform_trans_world_feat(p, x, reference_points, n_heads=8, n_points=4, strid
     m = F.relu(F.conv2d(mem, p["merge_linear.0.weight"], p["merge_linear.0.bias"]))
     m = F.interpolate(m, size=(H, W), mode="bilinear", align_corners=False)
     return F.relu(F.conv2d(m, p["upsample.1.weight"], p["upsample.1.bias"], padding=1))
+
+
+def conv_world_feat(p, x):
+    """ConvWorldFeat.forward (multiview_detector/models/conv_world_feat.py:9-14,38-52, reduction=None), functional:
+    p = its state dict.  x [B, N, C, H, W] -> [B, C, H, W]."""
+    B, N, C, H, W = x.shape
+    y = F.relu(F.conv2d(x.reshape(B * N, C, H, W), p["downsample.0.weight"], p["downsample.0.bias"], stride=2, padding=1))
+    h, w = y.shape[-2:]
+    gx, gy = np.meshgrid(np.arange(w), np.arange(h))
+    coord = torch.stack([torch.from_numpy(gx / (w - 1) * 2 - 1).float(), torch.from_numpy(gy / (h - 1) * 2 - 1).float()], 0)
+    y = torch.cat([y.reshape(B, N * y.shape[1], h, w), coord.unsqueeze(0).repeat(B, 1, 1, 1)], 1)
+    y = F.relu(F.conv2d(y, p["world_feat.0.weight"], p["world_feat.0.bias"], padding=1))
+    y = F.relu(F.conv2d(y, p["world_feat.2.weight"], p["world_feat.2.bias"], padding=2, dilation=2))
+    y = F.relu(F.conv2d(y, p["world_feat.4.weight"], p["world_feat.4.bias"], padding=4, dilation=4))
+    y = F.interpolate(y, size=(H, W), mode="bilinear", align_corners=False)
+    return F.relu(F.conv2d(y, p["upsample.1.weight"], p["upsample.1.bias"], padding=1))

@@ -16,6 +16,7 @@ Fixtures:
                               weights, output (5-D reference points)
   pos_embedding.npz           create_pos_embedding((6,9),8) full tensor + (60,180),64 checksums
   world_feat_mini.npz         reference DeformTransWorldFeat mini forward (state dict + in/out)
+  conv_world_feat_mini.npz    reference ConvWorldFeat mini forward (state dict + in/out)
   geometry.npz                proj_mats / create_reference_map of the reference on a synthetic rig
   warp_restatement.npz        kornia-semantics warp from oracle/torch_oracle.py (NOT from kornia:
                               kornia is absent; flagged "unverified against kornia")
@@ -227,6 +228,21 @@ def gen_world_feat():
          dims=np.array([num_cam, Rworld[0], Rworld[1], base_dim, hidden, nhead, P]), **arrays)
 
 
+def gen_conv_world_feat():
+    """BASELINE config 0 (--world_feat conv): the reference's ConvWorldFeat (conv_world_feat.py:21-52)."""
+    from multiview_detector.models import conv_world_feat as ref_cwf
+    # (the class needs hidden_dim == base_dim: it views the down-sampled [B*N, hidden, h, w] as [B, N*base, h, w],
+    # conv_world_feat.py:44; reduction='sum' sums over the channel axis of a 4-D tensor and cannot run)
+    torch.manual_seed(17)
+    num_cam, Rworld, base_dim = 3, (8, 12), 8
+    model = ref_cwf.ConvWorldFeat(num_cam, list(Rworld), base_dim, hidden_dim=base_dim, stride=2).eval()
+    x = torch.randn(2, num_cam, base_dim, *Rworld)
+    with torch.no_grad():
+        y = model(x)
+    arrays = {"p." + k: npy(v) for k, v in model.state_dict().items()}
+    save("conv_world_feat_mini.npz", x=npy(x), out=npy(y), dims=np.array([num_cam, Rworld[0], Rworld[1], base_dim]), **arrays)
+
+
 # (a2, a4) geometry through the reference's own code ----------------------------------------------
 def gen_geometry():
     out = {}
@@ -287,5 +303,6 @@ if __name__ == "__main__":
     gen_module()
     gen_pos()
     gen_world_feat()
+    gen_conv_world_feat()
     gen_geometry()
     gen_warp()

@@ -56,17 +56,23 @@ def test_extension_module_name_and_signatures(built):
                    "grad_output", "im2col_step"]
 
 
-def test_cpu_tensors_raise_like_the_reference(built):
-    """ms_deform_attn.h:38: 'Not implemented on the CPU' -- there is no CPU fallback."""
+def test_cpu_tensors_run_on_the_librarys_own_host_path_and_fused_entry_stays_device_only(built):
+    """where the reference raises 'Not implemented on the CPU' (ms_deform_attn.h:38) CPU tensors run on
+    csrc/host_path.cpp -- never on the oracle (tests/test_host_path.py checks the numbers).  Mixed devices and the
+    fused inference entry (a device-only extension) still raise."""
+    import MultiScaleDeformableAttention as MSDA
     from mvdetr_amd.ops.functions import MSDeformAttnFunction
     from mvdetr_amd.ops import warp_perspective
-    v = torch.zeros(1, 4, 2, 2)
+    v = torch.ones(1, 4, 2, 2)
     s = torch.tensor([[2, 2]])
-    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
-        MSDeformAttnFunction.apply(v, s, torch.tensor([0]), torch.zeros(1, 1, 2, 1, 1, 2),
-                                   torch.zeros(1, 1, 2, 1, 1), 64)
-    with pytest.raises(RuntimeError, match="not implemented on the CPU"):
-        warp_perspective(torch.zeros(1, 2, 4, 4), torch.eye(3)[None], (4, 4))
+    out = MSDeformAttnFunction.apply(v, s, torch.tensor([0]), torch.full((1, 1, 2, 1, 1, 2), 0.5),
+                                     torch.ones(1, 1, 2, 1, 1), 64)
+    assert out.device.type == "cpu" and torch.allclose(out, torch.ones(1, 1, 4))
+    w = warp_perspective(torch.ones(1, 2, 4, 4), torch.eye(3)[None], (4, 4))
+    assert w.device.type == "cpu" and w.shape == (1, 2, 4, 4)
+    with pytest.raises(RuntimeError, match="CUDA tensor|Not implemented on the CPU"):
+        MSDA.ms_deform_attn_forward_fused(v, s, torch.tensor([0]), torch.zeros(1, 1, 1, 1, 2), torch.zeros(1, 1, 2, 1, 1, 2),
+                                          torch.zeros(1, 1, 2, 1, 1))
 
 
 def test_non_contiguous_raises(built):

@@ -739,14 +739,116 @@ def test_module_detects_a_shared_reference_point(ops):
     ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)[None].cuda()       # P equal copies
     with torch.no_grad():
         a = mod(query, ref, query, shapes, level_start_index(shapes))
-        assert mod._shared_ref_cache[1] is not None and mod._shared_ref_cache[1].shape == (1, S, L, 2)
+        assert mod._shared_ref_cache[2] is True and mod._shared_reference(ref).shape == (1, L, S, 2)   # level-major
         ref2 = ref.clone()
         ref2[0, 5, 2, 1, 0] += 0.01                                # one point differs: the full tensor is used
         b = mod(query, ref2, query, shapes, level_start_index(shapes))
-        assert mod._shared_ref_cache[1] is None
+        assert mod._shared_ref_cache[2] is False
         mod.fused_inference = False
         c = mod(query, ref, query, shapes, level_start_index(shapes))
     assert (a - c).abs().max().item() < 2e-5 and (a - b).abs().max().item() > 0
+
+
+def test_module_caches_survive_recycled_addresses_and_data_writes(ops):
+    """(1) a NEW reference tensor that lands on a freed tensor's address must not inherit its verdict or
+    its points; (2) parameter writes through .data (EMA swaps, constant_(w.data)) must reach the fused path."""
+    _, MSDA = ops
+    L, H, W, M, P, d_model = 3, 9, 14, 8, 4, 128
+    mod = _module_with_random_projections(d_model, L, M, P, seed=4).cuda().eval()
+    shapes = torch.tensor([[H, W]] * L).cuda()
+    lsi = level_start_index(shapes)
+    S = L * H * W
+    query = torch.randn(1, S, d_model, device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    base = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)[None]
+    with torch.no_grad():
+        for k in range(6):                                         # same shape, allocated and freed over and over
+            ref = (base + 0.01 * k).cuda()
+            if k % 2:
+                ref[0, :, :, 1:] += 0.02                           # odd rounds: the P points differ
+            got = mod(query, ref, query, shapes, lsi)
+            mod.fused_inference = False
+            want = mod(query, ref, query, shapes, lsi)
+            mod.fused_inference = True
+            assert (got - want).abs().max().item() < 2e-5, k
+            del ref
+        ref = base.cuda()
+        before = mod(query, ref, query, shapes, lsi)
+        mod.sampling_offsets.weight.data.normal_(0, 0.05)          # no version bump
+        mod.attention_weights.bias.data.add_(0.3 * torch.randn_like(mod.attention_weights.bias))
+        after = mod(query, ref, query, shapes, lsi)
+        mod.fused_inference = False
+        want = mod(query, ref, query, shapes, lsi)
+        assert (after - before).abs().max().item() > 1e-3 and (after - want).abs().max().item() < 2e-5
+        # the opt-in cache is the owner's promise that parameters are frozen; re-arming it picks up changes
+        mod.fused_inference = True
+        mod.cache_fused_projection(True)
+        c1 = mod(query, ref, query, shapes, lsi)
+        assert (c1 - want).abs().max().item() < 2e-5
+        mod.sampling_offsets.bias.data.add_(0.5)
+        mod.cache_fused_projection(True)
+        c2 = mod(query, ref, query, shapes, lsi)
+        assert (c2 - c1).abs().max().item() > 1e-3
+
+
+def test_module_fused_path_is_skipped_when_any_parameter_trains(ops):
+    """frozen offsets + trainable attention weights must still get gradients (the fused kernel is not
+    differentiable)."""
+    L, H, W, M, P, d_model = 3, 7, 9, 8, 4, 128
+    mod = _module_with_random_projections(d_model, L, M, P, seed=5).cuda()
+    for prm in mod.parameters():
+        prm.requires_grad_(False)
+    mod.attention_weights.weight.requires_grad_(True)
+    shapes = torch.tensor([[H, W]] * L).cuda()
+    S = L * H * W
+    query = torch.randn(1, S, d_model, device="cuda")
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)[None].cuda()
+    out = mod(query, ref, query, shapes, level_start_index(shapes))
+    out.square().mean().backward()
+    assert mod.attention_weights.weight.grad is not None and mod.attention_weights.weight.grad.abs().max().item() > 0
+
+
+@pytest.mark.parametrize("lv,D,M,B,ql", [([(13, 21)] * 7, 16, 8, 1, None), ([(9, 17)] * 6, 32, 4, 2, None), ([(8, 12)] * 12, 32, 2, 1, None),
+                                        ([(6, 9), (7, 11), (5, 8)], 16, 4, 1, None), ([(10, 14)] * 5, 16, 8, 1, (1, 3)),
+                                        ([(11, 13)] * 4, 16, 2, 2, None)])
+def test_fused_slice_interleaved_layout_equals_the_plain_layouts(ops, lv, D, M, B, ql):
+    """ABI v7: ONE raw tensor, slice-interleaved (MSDA.slice_major_rows), with query-major or level-major shared
+    reference points -- against the level-major two-tensor form and the oracle; group kernel, many-camera kernel,
+    unequal levels (tile body inside the group launch) and a query-level range (tile kernel)."""
+    _, MSDA = ops
+    P, L = 4, len(lv)
+    shapes = torch.tensor(lv)
+    lsi = level_start_index(shapes)
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(L * 100 + D)
+    value = torch.randn(B, S, M, D, generator=g)
+    q0, q1 = (0, S) if ql is None else (int(lsi[ql[0]]), int(lsi[ql[1]]) if ql[1] < L else S)
+    Lq = q1 - q0
+    # one reference point per (query, level): the query's own cell centre in every level + jitter
+    cells = torch.cat([torch.stack(torch.meshgrid(torch.arange(h) + 0.5, torch.arange(w) + 0.5, indexing="ij"), -1).reshape(-1, 2)
+                       / torch.tensor([h, w]) for h, w in lv])[q0:q1].flip(-1)                     # (x, y) in [0,1]
+    ref = (cells[None, :, None, :] + 0.01 * torch.randn(B, Lq, L, 2, generator=g)).contiguous()
+    off = 2.5 * torch.randn(B, Lq, M, L, P, 2, generator=g)
+    logit = torch.randn(B, Lq, M, L, P, generator=g)
+    rows = torch.tensor(MSDA.slice_major_rows(M, L, P, D))
+    raw = torch.cat([off.reshape(B, Lq, -1), logit.reshape(B, Lq, -1)], -1).index_select(-1, rows).contiguous()
+    kw = {} if ql is None else {"query_levels": ql}
+    dv = dev(value, shapes, lsi)
+    plain = MSDA.ms_deform_attn_forward_fused(*dv, ref.cuda(), off.cuda(), logit.cuda(), **kw)
+    a = MSDA.ms_deform_attn_forward_fused(*dv, ref.cuda(), None, None, raw=raw.cuda(), **kw)
+    b = MSDA.ms_deform_attn_forward_fused(*dv, ref.transpose(1, 2).contiguous().cuda(), None, None, raw=raw.cuda(),
+                                          ref_level_major=True, **kw)
+    # a wider GEMM output whose leading columns are the raw tensor
+    wide = torch.cat([raw, torch.randn(B, Lq, 8, generator=g)], -1).cuda()
+    c = MSDA.ms_deform_attn_forward_fused(*dv, ref.cuda(), None, None, raw=wide, **kw)
+    for got in (a, b, c):
+        assert (got - plain).abs().max().item() < 2e-5
+    loc = torch_oracle.msda_sampling_locations(ref[:, :, :, None, :].expand(B, Lq, L, P, 2), off, shapes)
+    want = torch_oracle.msda_core(value, shapes, loc, torch.softmax(logit.flatten(-2), -1).view_as(logit))
+    assert (a.cpu() - want).abs().max().item() < FP32_TOL
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward_fused(*dv, ref.cuda(), off.cuda(), None, raw=raw.cuda(), **kw)
 
 
 # ---- seeded sweep over encoder-shaped configurations: every dispatch route against the oracle -------------------

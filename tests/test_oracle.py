@@ -102,6 +102,25 @@ def test_world_feat_mini():
     assert (out - t(g["out"])).abs().max().item() < 1e-5
 
 
+def test_conv_world_feat_mini():
+    """BASELINE config 0's world-feature block: oracle restatement AND the product module (plain torch, runs on the
+    CPU) against the reference's own output (conv_world_feat.py:21-52)."""
+    from mvdetr_amd.world_feat import ConvWorldFeat
+    g = load_golden("conv_world_feat_mini.npz")
+    num_cam, H, W, base_dim = (int(x) for x in g["dims"])
+    params = {k[2:]: t(v) for k, v in g.items() if k.startswith("p.")}
+    want = t(g["out"])
+    out = torch_oracle.conv_world_feat(params, t(g["x"]))
+    assert out.shape == want.shape and (out - want).abs().max().item() < 1e-6
+    mod = ConvWorldFeat(num_cam, (H, W), base_dim, hidden_dim=base_dim).eval()
+    missing, unexpected = mod.load_state_dict(params, strict=True)        # same parameter names as the reference
+    with torch.no_grad():
+        got = mod(t(g["x"]))
+    assert (got - want).abs().max().item() < 1e-6
+    with pytest.raises(ValueError):
+        ConvWorldFeat(num_cam, (H, W), base_dim, hidden_dim=base_dim * 2)
+
+
 # ---- (8) warp: C restatement vs torch restatement (both unpinned against kornia itself) -------------
 def test_warp_c_vs_torch_restatement():
     g = load_golden("warp_restatement.npz")
