@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="wildtrack", choices=["wildtrack", "multiviewx", "stress16"])
+    ap.add_argument("--arch", default="resnet18", choices=["resnet18", "resnet50"],
+                    help="trunk (out of the path's scope; resnet50 + --config multiviewx --batch 4 is BASELINE configs[3])")
     ap.add_argument("--parallel", default="dp", choices=["dp", "views"])
     ap.add_argument("--encoder", default="sharded", choices=["sharded", "replicated"],
                     help="--parallel views only: shadow transformer partitioned by camera, or replicated")
@@ -237,7 +239,8 @@ def main():
             import tempfile
             tun = torch.cuda.tunable
             tun.set_filename(os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_{os.getpid()}.csv"))
-            tun.write_file_on_exit(False)
+            if hasattr(tun, "write_file_on_exit"):         # (not in every torch build; the results file is scratch anyway)
+                tun.write_file_on_exit(False)
             tun.set_max_tuning_duration(200)
             tun.enable(True)
             tun.tuning_enable(True)
@@ -258,7 +261,7 @@ def main():
     timer = KernelTimer(MSDA)      # callers look the functions up on the module at call time
 
     geom = geometry.GEOMETRIES[a.config]
-    model = build_model(a.config, seed=0)
+    model = build_model(a.config, seed=0, arch=a.arch)
     offset_std = perturb_sampling(model, a.offset_std_px)
     model = model.to(dev).eval()
     attn_layers = [layer.self_attn for layer in model.world_feat.encoder.layers] if hasattr(model.world_feat, "encoder") else []
@@ -356,7 +359,7 @@ def main():
         "n_gpus": n_ranks, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{a.config} {N}-cam frame, --world_feat deform_trans, ResNet18 trunk: "
+        "config": {"workload": f"{a.config} {N}-cam frame, --world_feat deform_trans, {a.arch} trunk: "
                                f"{N}x3x{Hi}x{Wi} -> {geom.feat_channels}-ch world feat {geom.Rworld_shape[0]}x{geom.Rworld_shape[1]} "
                                f"-> BEV (BASELINE.json configs[1])" if a.config == "wildtrack" else f"{a.config} {N}-cam frame",
                    "frames_per_step": frames_per_step, "batch_per_rank": Bf, "parallelism": f"{a.parallel}{world}" + (f"-{a.encoder}" if a.parallel == "views" and world > 1 else ""),

@@ -83,7 +83,6 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
     const int my_part = tid % Cfg::PARTS, my_slot = tid / Cfg::PARTS;
     const int my_row0 = my_slot / WW, my_col = my_slot % WW;
     const bool col_ok = my_row0 < RPP;
-    float *const st_dst = vwin + (my_row0 * WW + my_col) * SLICE + my_part * 4;
 
     // t enumerates xcd x (unit of that xcd) x query level: the L query levels (cameras) of one (tile, slice) run
     // back to back on one XCD, so all but the first find the source windows in that L2 (as in msda_tile_body.h)
@@ -115,23 +114,26 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
             if (l >= L) continue;                             // (uniform; `break` would keep the loop from unrolling)
             __syncthreads();                                  // everyone is done reading the old window
             {
+                // window copy by LDS-DMA (buffer_load ... lds), as in msda_forward_group.hip: a wave's 64 lanes are the
+                // 8 x 16-byte chunks of 8 consecutive window positions = 1 KB contiguous in LDS behind a wave-uniform
+                // base; no staging registers (the register-staged copy held 80 of them), no ds_write; positions outside
+                // the level are out-of-range reads and store zeros
+                const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(vbatch), 0, (int)((unsigned)S * (unsigned)row * 4u - (unsigned)(hs * SLICE) * 4u), 0x00020000);
                 const int gx = ox + my_col;
-                const bool xok = col_ok && (unsigned)gx < (unsigned)Wq;
-                const float *colp = vbatch + lsi[l] * row + my_part * 4 + (xok ? gx : 0) * row;
-                float4 stage[NSTAGE];
-#pragma unroll
-                for (int i = 0; i < NSTAGE; ++i) {
-                    const int wy = RPP == 1 ? i : my_row0 + i * RPP;
-                    const int gy = oy + wy;
-                    stage[i] = make_float4(0, 0, 0, 0);
-                    if (xok && wy < WH && (unsigned)gy < (unsigned)Hq)
-                        stage[i] = *reinterpret_cast<const float4 *>(colp + (int64_t)gy * Wq * row);
-                }
+                const bool xok = (unsigned)gx < (unsigned)Wq;
+                const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const unsigned so = (unsigned)((int)lsi[l] * (int)row) * 4u;
                 if (col_ok) {
 #pragma unroll
-                    for (int i = 0; i < NSTAGE; ++i)
-                        if ((RPP == 1 ? i : my_row0 + i * RPP) < WH)
-                            *reinterpret_cast<float4 *>(st_dst + i * RPP * WW * SLICE) = stage[i];
+                    for (int i = 0; i < NSTAGE; ++i) {
+                        const int wy = my_row0 + i * RPP, gy = oy + wy;
+                        if (wy < WH) {
+                            const unsigned vo = (xok && (unsigned)gy < (unsigned)Hq) ? (unsigned)((gy * Wq + gx) * (int)row + my_part * 4) * 4u : 0x80000000u;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(vwin + (i * RPP * WW + wave_u * 8) * SLICE),
+                                                                     16, (int)vo, (int)so, 0, 0);
+                        }
+                    }
                 }
             }
             const float4 la = *reinterpret_cast<const float4 *>(loc + (e0 + l * P) * 2);

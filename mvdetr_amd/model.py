@@ -37,9 +37,37 @@ class BasicBlock(nn.Module):
         return self.relu(out + identity)
 
 
-def resnet18_trunk(replace_stride_with_dilation=(False, True, True), in_channels=3) -> nn.Sequential:
+class Bottleneck(nn.Module):
+    """1x1 - 3x3 (strided / dilated) - 1x1 residual block, expansion 4 (resnet.py:72-112): the block of the
+    ResNet-50 that BASELINE.json's configs[3] names.  The reference defines resnet50 (resnet.py:244) but wires only
+    vgg11 / resnet18 into the detector (mvdetr.py:97-107)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+def resnet_trunk(depth=18, replace_stride_with_dilation=(False, True, True), in_channels=3) -> nn.Sequential:
     """conv1, bn1, relu, maxpool, layer1..4 as one Sequential (the reference slices
-    list(resnet18(...).children())[:-2], mvdetr.py:103-105)."""
+    list(resnet18(...).children())[:-2], mvdetr.py:103-105).  depth 18: BasicBlock x [2,2,2,2], 512 channels out;
+    depth 50: Bottleneck x [3,4,6,3], 2048 channels out (resnet.py:226-250)."""
+    block, counts = {18: (BasicBlock, (2, 2, 2, 2)), 50: (Bottleneck, (3, 4, 6, 3))}[depth]
+    exp = getattr(block, "expansion", 1)
     state = {"inplanes": 64, "dilation": 1}
 
     def make_layer(planes, blocks, stride=1, dilate=False):
@@ -48,22 +76,26 @@ def resnet18_trunk(replace_stride_with_dilation=(False, True, True), in_channels
             state["dilation"] *= stride
             stride = 1
         down = None
-        if stride != 1 or state["inplanes"] != planes:
-            down = nn.Sequential(nn.Conv2d(state["inplanes"], planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
-        layers = [BasicBlock(state["inplanes"], planes, stride, down, prev)]
-        state["inplanes"] = planes
-        layers += [BasicBlock(planes, planes, dilation=state["dilation"]) for _ in range(1, blocks)]
+        if stride != 1 or state["inplanes"] != planes * exp:
+            down = nn.Sequential(nn.Conv2d(state["inplanes"], planes * exp, 1, stride, bias=False), nn.BatchNorm2d(planes * exp))
+        layers = [block(state["inplanes"], planes, stride, down, prev)]
+        state["inplanes"] = planes * exp
+        layers += [block(planes * exp, planes, dilation=state["dilation"]) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
     trunk = nn.Sequential(
         nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
         nn.MaxPool2d(3, 2, 1),
-        make_layer(64, 2), make_layer(128, 2, 2, replace_stride_with_dilation[0]),
-        make_layer(256, 2, 2, replace_stride_with_dilation[1]), make_layer(512, 2, 2, replace_stride_with_dilation[2]))
+        make_layer(64, counts[0]), make_layer(128, counts[1], 2, replace_stride_with_dilation[0]),
+        make_layer(256, counts[2], 2, replace_stride_with_dilation[1]), make_layer(512, counts[3], 2, replace_stride_with_dilation[2]))
     for m in trunk.modules():
         if isinstance(m, nn.Conv2d):
             nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
     return trunk
+
+
+def resnet18_trunk(replace_stride_with_dilation=(False, True, True), in_channels=3) -> nn.Sequential:
+    return resnet_trunk(18, replace_stride_with_dilation, in_channels)
 
 
 def output_head(in_dim, feat_dim, out_dim):
@@ -84,10 +116,11 @@ class MVDeTr(nn.Module):
         bottleneck_dim = geom.feat_channels if bottleneck_dim is None else bottleneck_dim
         # image pixel -> reduced world grid, fp64 (mvdetr.py:82-95)
         self.register_buffer("proj_mats", torch.from_numpy(geometry.build_proj_mats(geom, Ks, Rts, z)), persistent=False)
-        if arch != "resnet18":
-            raise ValueError("the minimal caller wires ResNet-18 only (the reference: vgg11/resnet18)")
-        self.base = resnet18_trunk()
-        base_dim = 512
+        if arch not in ("resnet18", "resnet50"):
+            raise ValueError("trunks: resnet18 (the reference's default, mvdetr.py:102-105) or resnet50 (BASELINE configs[3]; "
+                             "resnet.py:244); vgg11 is not provided")
+        self.base = resnet_trunk(int(arch[6:]))
+        base_dim = 512 if arch == "resnet18" else 2048
         if bottleneck_dim:
             self.bottleneck = nn.Sequential(nn.Conv2d(base_dim, bottleneck_dim, 1), nn.Dropout2d(dropout))
             base_dim = bottleneck_dim

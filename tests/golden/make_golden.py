@@ -18,8 +18,10 @@ Fixtures:
   world_feat_mini.npz         reference DeformTransWorldFeat mini forward (state dict + in/out)
   conv_world_feat_mini.npz    reference ConvWorldFeat mini forward (state dict + in/out)
   geometry.npz                proj_mats / create_reference_map of the reference on a synthetic rig
-  warp_restatement.npz        kornia-semantics warp from oracle/torch_oracle.py (NOT from kornia:
-                              kornia is absent; flagged "unverified against kornia")
+  warp_restatement.npz        kornia-0.5-semantics warp by an independent fp64 numpy closed form in THIS script (not from
+                              oracle/, not from kornia: kornia is absent; flagged "unverified against kornia")
+  warp_convention.npz         where feature pixels land on the world grid according to the reference's own projection
+                              code (mvdetr.py:82-95,155-161; utils/projection.py:4-14): pins direction / composition
 """
 import os
 import sys
@@ -279,7 +281,30 @@ def gen_geometry():
     save("geometry.npz", **out)
 
 
-# (8) warp: our restatement (flagged) --------------------------------------------------------------
+# (8) warp ---------------------------------------------------------------------------------------------------------
+def _closed_form_warp(src, M, dsize):
+    """Independent fp64 closed form of what kornia 0.5's warp_perspective(bilinear, zeros, align_corners=False) computes
+    (SURVEY 8a-1), written with numpy only -- NOT through oracle/: output pixel (i, j) samples the source at
+    p = M^-1 (j, i, 1), x = p_x / p_z * w / (w - 1) - 0.5, y = p_y / p_z * h / (h - 1) - 0.5, bilinear, zeros outside."""
+    n, c, h, w = src.shape
+    H, W = dsize
+    out = np.zeros((n, c, H, W))
+    jj, ii = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    for v in range(n):
+        p = np.linalg.inv(M[v]) @ np.stack([jj.ravel(), ii.ravel(), np.ones(H * W)])
+        x = p[0] / p[2] * w / (w - 1) - 0.5
+        y = p[1] / p[2] * h / (h - 1) - 0.5
+        x0, y0 = np.floor(x), np.floor(y)
+        acc = np.zeros((c, H * W))
+        for dy, wy in ((0, 1 - (y - y0)), (1, y - y0)):
+            for dx, wx in ((0, 1 - (x - x0)), (1, x - x0)):
+                yy, xx = (y0 + dy).astype(np.int64), (x0 + dx).astype(np.int64)
+                ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+                acc += np.where(ok, wy * wx, 0.0) * src[v][:, np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)]
+        out[v] = acc.reshape(c, H, W)
+    return out
+
+
 def gen_warp():
     g = torch.Generator().manual_seed(17)
     src = torch.randn(2, 8, 9, 16, generator=g, dtype=torch.float64)
@@ -288,12 +313,46 @@ def gen_warp():
     pm = geometry.build_proj_mats(geom, Ks, Rts)[:2]
     # scale to the mini feature map: world grid 12x36 instead of 120x360, feature 9x16 instead of 90x160
     shrink = np.diag([0.1, 0.1, 1.0])
-    Mfull = torch.from_numpy(np.stack([shrink @ pm[i] @ np.diag([120.0, 120.0, 1.0]) for i in range(2)]))
-    out64 = torch_oracle.warp_perspective(src, Mfull, (12, 36))
-    out32 = torch_oracle.warp_perspective(src.float(), Mfull.float(), (12, 36))
-    grid = torch_oracle.warp_grid(Mfull, (9, 16), (12, 36))
-    save("warp_restatement.npz", src=npy(src), M=npy(Mfull), out=npy(out64), out_f32=npy(out32),
-         grid=npy(grid), note=np.array("kornia-semantics restatement, unverified against kornia (absent)"))
+    Mfull = np.stack([shrink @ pm[i] @ np.diag([120.0, 120.0, 1.0]) for i in range(2)])
+    out64 = _closed_form_warp(npy(src), Mfull, (12, 36))
+    save("warp_restatement.npz", src=npy(src), M=Mfull, out=out64,
+         note=np.array("independent numpy closed form of kornia 0.5 semantics; unverified against kornia itself (absent): "
+                       "the (size/(size-1)) normalisation quirk rests on SURVEY 8a-1"))
+
+
+def gen_warp_convention():
+    """What CAN be pinned to the reference without kornia: direction and composition of the homography.  The reference's
+    own code (MVDeTr.__init__ + the per-forward lines mvdetr.py:155-161, utils/projection.py:4-14) says where a feature
+    pixel (u, v) lies on the reduced world grid; a blob at (u, v) warped by the build must come out there."""
+    from multiview_detector.models import mvdetr as ref_mvdetr
+    from multiview_detector.utils import projection as ref_proj
+    geom = geometry.WILDTRACK
+    Ks, Rts = geometry.synthetic_rig(geom, seed=0)
+    base = types.SimpleNamespace(
+        worldcoord_from_worldgrid_mat=geom.worldcoord_from_worldgrid_mat, world_indexing_from_xy_mat=geom.world_indexing_from_xy_mat,
+        intrinsic_matrices=Ks, extrinsic_matrices=Rts, worldcoord_unit=geom.worldcoord_unit)
+    ds = types.SimpleNamespace(base=base, num_cam=geom.num_cam, Rworld_shape=list(geom.Rworld_shape),
+                               Rimg_shape=list(geom.Rimg_shape), world_reduce=geom.world_reduce, img_reduce=geom.img_reduce)
+    ref_mvdetr.resnet18 = lambda **kw: torch.nn.Sequential(torch.nn.Identity(), torch.nn.Identity(), torch.nn.Identity())
+    model = ref_mvdetr.MVDeTr(ds, "resnet18", world_feat_arch="conv", bottleneck_dim=0)
+    N = 3
+    Maug = torch.eye(3).repeat(N, 1, 1)
+    img_from_Rimg = torch.inverse(Maug) @ torch.from_numpy(np.diag([geom.img_reduce, geom.img_reduce, 1.0])).view(1, 3, 3).repeat(N, 1, 1).float()
+    frame_proj = (model.proj_mats[:N].float() @ img_from_Rimg).double().numpy()       # Rworldgrid(xy) <- Rimggrid(xy)
+    h, w = geom.Rimg_shape
+    H, W = geom.Rworld_shape
+    rng = np.random.default_rng(5)
+    uv, xy = [], []
+    for cam in range(N):
+        pts = []
+        while len(pts) < 6:
+            u, v = rng.uniform(8, w - 8), rng.uniform(h * 0.45, h - 6)
+            X, Y = ref_proj.project_2d_points(frame_proj[cam], np.array([[u], [v]]))[:, 0]
+            if 6 < X < W - 6 and 6 < Y < H - 6:
+                pts.append((u, v, X, Y))
+        uv.append([(p[0], p[1]) for p in pts])
+        xy.append([(p[2], p[3]) for p in pts])
+    save("warp_convention.npz", M=frame_proj, src_uv=np.array(uv), dst_xy=np.array(xy), dims=np.array([N, h, w, H, W]))
 
 
 if __name__ == "__main__":
@@ -306,3 +365,4 @@ if __name__ == "__main__":
     gen_conv_world_feat()
     gen_geometry()
     gen_warp()
+    gen_warp_convention()

@@ -1,0 +1,59 @@
+"""The caller model on CPU tensors, through the product's own host path (no GPU): BASELINE.json configs[0]
+(--world_feat conv, "PyTorch CPU-only"), the deform_trans path the reference cannot run without CUDA, and the
+ResNet-50 trunk of configs[3]."""
+import pytest
+import torch
+
+from mvdetr_amd import geometry
+from mvdetr_amd.model import build_model
+from oracle import frame_oracle, torch_oracle
+
+
+def _inputs(seed=3):
+    g = torch.Generator().manual_seed(seed)
+    imgs = torch.randn(1, 3, 3, *geometry.MINI.input_img_shape, generator=g)
+    M = geometry.random_affine_mats(1, 3, geometry.MINI.input_img_shape, seed=2, translate=0.05, scale=(0.9, 1.1))
+    return imgs, M
+
+
+def test_config0_conv_world_feat_runs_on_the_cpu_and_matches_the_oracle():
+    model = build_model("mini", seed=0, world_feat_arch="conv", channels_last=False).eval()
+    imgs, M = _inputs()
+    with torch.no_grad():
+        (wh, wo), (ih, io, iw) = model(imgs, M)
+        assert wh.shape == (1, 1, 24, 72) and wo.shape == (1, 2, 24, 72) and ih.shape == (3, 1, 18, 32)
+        # same features through the oracle's warp + ConvWorldFeat restatement
+        feat = model.features(imgs)
+        proj = model.frame_proj_mats(M)
+        world = torch_oracle.warp_perspective(feat, proj, model.Rworld_shape).view(1, 3, -1, *model.Rworld_shape)
+        p = {k[len("world_feat."):]: v for k, v in model.state_dict().items() if k.startswith("world_feat.")}
+        want = torch_oracle.conv_world_feat(p, world)
+        got = model.hot_path(feat, proj)
+    assert (got - want).abs().max().item() < 1e-4
+
+
+def test_deform_trans_frame_on_the_cpu_matches_the_frame_oracle():
+    """The reference's MSDeformAttn raises on CPU tensors; here the whole frame runs on csrc/host_path.cpp."""
+    model = build_model("mini", seed=0, channels_last=False).eval()
+    with torch.no_grad():
+        for layer in model.world_feat.encoder.layers:
+            layer.self_attn.sampling_offsets.weight.normal_(0, 0.02)
+            layer.self_attn.attention_weights.weight.normal_(0, 0.05)
+    imgs, M = _inputs()
+    with torch.no_grad():
+        (wh, wo), _ = model(imgs, M)
+        p = {k: v.detach() for k, v in model.state_dict().items()}
+        ref = model.world_feat.encoder.reference_points
+        (rwh, rwo), _ = frame_oracle.forward(p, imgs, model.frame_proj_mats(M), model.Rworld_shape, ref, 3)
+    assert (wh - rwh).abs().max().item() < 1e-4 and (wo - rwo).abs().max().item() < 1e-4
+
+
+def test_resnet50_trunk_is_wired():
+    model = build_model("mini", seed=0, arch="resnet50", channels_last=False).eval()
+    assert sum(p.numel() for p in model.base.parameters()) == 23_508_032          # torchvision's resnet50 without fc
+    imgs, M = _inputs()
+    with torch.no_grad():
+        (wh, wo), (ih, _, _) = model(imgs, M)
+    assert wh.shape == (1, 1, 24, 72) and ih.shape == (3, 1, 18, 32) and torch.isfinite(wh).all()
+    with pytest.raises(ValueError):
+        build_model("mini", arch="vgg11")

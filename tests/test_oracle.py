@@ -121,12 +121,14 @@ def test_conv_world_feat_mini():
         ConvWorldFeat(num_cam, (H, W), base_dim, hidden_dim=base_dim * 2)
 
 
-# ---- (8) warp: C restatement vs torch restatement (both unpinned against kornia itself) -------------
-def test_warp_c_vs_torch_restatement():
+# ---- (8) warp: both restatements against the golden's INDEPENDENT fp64 closed form (tests/golden/make_golden.py,
+# numpy only); none of it is pinned against kornia itself, which is absent -- see test_warp_convention_* for what the
+# reference's own code does pin ------------------------------------------------------------------------------------
+def test_warp_restatements_vs_independent_closed_form():
     g = load_golden("warp_restatement.npz")
     src, M = t(g["src"]), t(g["M"])
     out64 = torch_oracle.warp_perspective(src, M, (12, 36))
-    assert torch.equal(out64, t(g["out"]))
+    assert (out64 - t(g["out"])).abs().max().item() < 1e-12
     c64 = c_oracle.warp_perspective(src, M, (12, 36))
     assert (c64 - out64).abs().max().item() < 1e-10
     c32 = c_oracle.warp_perspective(src.float(), M.float(), (12, 36))
@@ -150,6 +152,42 @@ def test_warp_net_effect_formula():
     px, py = p[..., 0] / p[..., 2], p[..., 1] / p[..., 2]
     assert (x - (px * 16 / 15 - 0.5)).abs().max().item() < 1e-9
     assert (y - (py * 9 / 8 - 0.5)).abs().max().item() < 1e-9
+
+
+def _blob_centroids(warp_fn, g):
+    """Warp one Gaussian blob per pinned feature pixel and return the intensity centroid of its image, per point."""
+    N, h, w, H, W = (int(x) for x in g["dims"])
+    uv, M = g["src_uv"], t(g["M"])
+    K = uv.shape[1]
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float64), torch.arange(w, dtype=torch.float64), indexing="ij")
+    src = torch.stack([torch.stack([torch.exp(-((xs - uv[n, k, 0]) ** 2 + (ys - uv[n, k, 1]) ** 2) / (2 * 1.2 ** 2))
+                                    for k in range(K)]) for n in range(N)])            # [N, K, h, w]: channel k = blob k
+    out = warp_fn(src, M, (H, W)).double()
+    Y, X = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    mass = out.sum((-1, -2))
+    assert (mass > 0.5).all()
+    return torch.stack([(out * X).sum((-1, -2)) / mass, (out * Y).sum((-1, -2)) / mass], -1)      # [N, K, 2] (x, y)
+
+
+def check_warp_convention(warp_fn, g):
+    """A feature-pixel blob must come out on the world grid where the REFERENCE's projection code puts that pixel
+    (mvdetr.py:82-95,155-161 + utils/projection.py:4-14, recorded in warp_convention.npz): pins the direction of the
+    homography (dst <- src), the (x, y) order and the composition.  Tolerance: the blob is stretched by the ground-plane
+    magnification (its centroid moves by a pixel or two) and kornia's size/(size-1) quirk shifts it by < 1 px; a wrong
+    convention is off by tens of pixels (asserted too)."""
+    want = t(g["dst_xy"])
+    got = _blob_centroids(warp_fn, g)
+    dist = (got - want).norm(dim=-1)
+    assert dist.max().item() < 3.0, dist
+    # the transposed and the inverse convention would not pass
+    assert (got.flip(-1) - want).norm(dim=-1).min().item() > 10
+    return dist
+
+
+def test_warp_convention_pinned_to_the_reference_projection_code():
+    g = load_golden("warp_convention.npz")
+    check_warp_convention(lambda s_, M_, d_: torch_oracle.warp_perspective(s_, M_, d_), g)
+    check_warp_convention(lambda s_, M_, d_: c_oracle.warp_perspective(s_, M_, d_), g)
 
 
 def test_warp_backward_c_vs_autograd():

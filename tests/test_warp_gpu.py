@@ -32,7 +32,26 @@ def test_golden_fixture(warp):
     assert (out64 - t(g["out"])).abs().max().item() < 1e-11
     out32 = warp(src.float().cuda(), M.float(), (12, 36)).cpu()
     assert (out32.double() - t(g["out"])).abs().max().item() < 1e-4
-    assert (out32 - t(g["out_f32"])).abs().max().item() < 1e-4
+
+
+def test_convention_pinned_to_the_reference_projection_code(warp):
+    """tests/test_oracle.py::check_warp_convention on the HIP kernel (fp32 and fp64, NCHW and channel-last output)."""
+    from test_oracle import check_warp_convention
+    g = load_golden("warp_convention.npz")
+    check_warp_convention(lambda s_, M_, d_: warp(s_.cuda(), M_, d_).cpu(), g)
+    check_warp_convention(lambda s_, M_, d_: warp(s_.float().cuda(), M_.float(), d_).cpu(), g)
+    check_warp_convention(lambda s_, M_, d_: warp(s_.float().cuda(), M_.float(), d_, channels_last_out=True).permute(0, 3, 1, 2).cpu(), g)
+
+
+def test_nearest_mode_equals_grid_sample_nearest(warp):
+    """kornia.warp_perspective(..., 'nearest') of frameDataset.py:80 (ground-plane masks)."""
+    g = load_golden("warp_restatement.npz")
+    src, M = t(g["src"]), t(g["M"])
+    want = torch_oracle.warp_perspective(src, M, (12, 36), mode="nearest")
+    got = warp(src.cuda(), M, (12, 36), "nearest").cpu()
+    assert torch.equal(got, want)
+    got32 = warp(src.float().cuda(), M.float(), (12, 36), mode="nearest", channels_last_out=True).cpu().permute(0, 3, 1, 2)
+    assert (got32.double() - want).abs().max().item() < 1e-6          # same texels (fp64 geometry), fp32 values
 
 
 def _against_both_oracles(out, src, M, frac_within=0.99):
@@ -121,7 +140,9 @@ def test_degenerate_and_misuse(warp):
     # empty
     assert warp(src[:0], far[:0], (7, 9)).shape == (0, 4, 7, 9)
     with pytest.raises(NotImplementedError):
-        warp(src, far, (7, 9), "nearest")
+        warp(src, far, (7, 9), "bicubic")
+    with pytest.raises(NotImplementedError):
+        warp(src, far, (7, 9), padding_mode="border")
     with pytest.raises(ValueError):
         warp(src, far.repeat(2, 1, 1), (7, 9))
 
