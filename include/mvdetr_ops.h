@@ -186,6 +186,11 @@ const char *mvdetr_msda_last_forward_kernel(void);
  * Initial value comes from MVDETR_MSDA_FWD_IMPL = auto | gather | tile. */
 int mvdetr_msda_set_forward_impl(int impl);
 
+/* dst[n][c][r] = src[n][r][c]: layout change between NCHW (rows = channels, cols = h*w) and the channel-last layout the
+ * fast warp kernels read, and back.  Tiled through LDS, both sides move in 256-byte runs. */
+int mvdetr_transpose_f32(void *stream, const float *src, int n, int rows, int cols, float *dst);
+int mvdetr_transpose_f64(void *stream, const double *src, int n, int rows, int cols, double *dst);
+
 /* ---- CPU path (host pointers, no stream, synchronous) ------------------------------------------------------------
  * The reference extension raises for CPU tensors (ms_deform_attn_cpu.cpp:17-41 are stubs; ms_deform_attn.h:38,60).
  * These entry points make the same contracts work on host memory: same argument meaning and layouts as the device

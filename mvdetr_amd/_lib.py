@@ -46,6 +46,8 @@ SIGNATURES = {
     "mvdetr_warp_perspective_forward_f64": (_WARP, _i),
     "mvdetr_warp_perspective_backward_f32": (_WARP, _i),
     "mvdetr_warp_perspective_backward_f64": (_WARP, _i),
+    "mvdetr_transpose_f32": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "mvdetr_transpose_f64": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "mvdetr_msda_forward_host_f32": (_MSDA_FWD_HOST, _i),
     "mvdetr_msda_forward_host_f64": (_MSDA_FWD_HOST, _i),
     "mvdetr_msda_backward_host_f32": (_MSDA_BWD_HOST, _i),

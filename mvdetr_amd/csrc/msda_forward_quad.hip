@@ -362,12 +362,12 @@ __global__ __launch_bounds__(quad::THREADS, 3) void msda_fwd_quad(
             }
             // branch-free on purpose: with control flow inside the camera loop the compiler sinks every camera's FMAs
             // below the whole loop and spills the LDS data they wait for
-            const bool in = active & (fabsf(x - cx) < 0.5f * (WW - 1)) & (fabsf(y - cy) < 0.5f * (WH - 1));
+            const bool in = (int)active & (int)(fabsf(x - cx) < 0.5f * (WW - 1)) & (int)(fabsf(y - cy) < 0.5f * (WH - 1));
             const float fx = floorf(x), fy = floorf(y);
             const int ix = in ? (int)fx - ox : 0, iy = in ? (int)fy - oy : 0;
             const float wx1 = in ? x - fx : 0.f, wy1 = in ? y - fy : 0.f;   // (NaN locations must not leak into the weights)
             a = in ? a : 0.f;
-            miss[c >> 2] |= (active & !in) ? 1u << (l + 8 * (c & 3)) : 0u;
+            miss[c >> 2] |= ((int)active & (int)!in) ? 1u << (l + 8 * (c & 3)) : 0u;
             const int s = (ix ^ role) & 1;                 // 1: the right-hand corner has this quad's parity
             const float wxA = s ? wx1 : 1.f - wx1;
             const float ay1 = wy1 * a, ay0 = a - ay1;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(quad::THREADS, 3) void msda_fwd_quad(
         __syncthreads();
 
         for (int l = 0; l < L; ++l) {
-            const int tr = wave * 128 + l * 16;
+            [[maybe_unused]] const int tr = wave * 128 + l * 16;
             QTRACE(tr + 0);
             const bool more = l + 1 < L;
             const char *lane_base = reinterpret_cast<const char *>(win + (l & 1) * WIN_FLOATS) + lane_byte;

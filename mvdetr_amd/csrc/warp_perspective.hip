@@ -376,9 +376,52 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
     return (int)hipGetLastError();
 }
 
+// [n, rows, cols] -> [n, cols, rows] through a 64 x 64 LDS tile (reads and writes both in 256-byte runs): turns an NCHW
+// feature map into the channel-last layout the fast warp kernels read (rows = C, cols = h*w) and back
+// (rows = h*w, cols = C).
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_tiles(const T *__restrict__ src, int rows, int cols, T *__restrict__ dst)
+{
+    __shared__ T tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int64_t base = (int64_t)blockIdx.z * rows * cols;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + ty + 4 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 4 * k][tx] = src[base + (int64_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + ty + 4 * k, r = r0 + tx;
+        if (r < rows && c < cols) dst[base + (int64_t)c * rows + r] = tile[tx][ty + 4 * k];
+    }
+}
+
+template <typename T> static int transpose_entry(void *stream, const T *src, int n, int rows, int cols, T *dst)
+{
+    if (n < 0 || rows < 0 || cols < 0) return (int)hipErrorInvalidValue;
+    if ((int64_t)n * rows * cols == 0) return 0;
+    if (!src || !dst || n > 65535 || (rows + 63) / 64 > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((transpose_tiles<T>), dim3((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)n), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), src, rows, cols, dst);
+    return (int)hipGetLastError();
+}
+
 }  // namespace mvdetr
 
 extern "C" {
+
+int mvdetr_transpose_f32(void *stream, const float *src, int n, int rows, int cols, float *dst)
+{
+    return mvdetr::transpose_entry<float>(stream, src, n, rows, cols, dst);
+}
+int mvdetr_transpose_f64(void *stream, const double *src, int n, int rows, int cols, double *dst)
+{
+    return mvdetr::transpose_entry<double>(stream, src, n, rows, cols, dst);
+}
+
 
 int mvdetr_warp_perspective_forward_f32(void *stream, const float *src, const float *M, int n,
                                         int channels, int src_h, int src_w, int dst_h, int dst_w,

@@ -96,9 +96,10 @@ def test_channels_last_output_equals_permuted(warp):
     M = wildtrack_mats(3)
     src = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(1)).cuda()
     a = warp(src, M, (120, 360))
-    b = warp(src, M, (120, 360), channels_last_out=True)
+    b = warp(src, M, (120, 360), channels_last_out=True)          # (tiled transpose + the channel-last kernel)
     assert b.shape == (7, 120, 360, 128)
-    assert torch.equal(a.permute(0, 2, 3, 1), b)
+    assert (a.permute(0, 2, 3, 1) - b).abs().max().item() < 2e-6   # same weights, possibly another fma contraction
+    assert torch.equal(a.permute(0, 2, 3, 1) == 0, b == 0)
     # ragged channel / pixel counts (not multiples of 64)
     src = torch.randn(3, 37, 11, 13, generator=torch.Generator().manual_seed(2)).cuda()
     Ms = wildtrack_mats(None)[:3] @ torch.diag(torch.tensor([12.0, 12.0, 1.0]))
@@ -183,9 +184,16 @@ def test_channels_last_source_wildtrack(warp, aug, monkeypatch):
     assert out.shape == (7, 120, 360, 128) and out.is_contiguous()
     _against_both_oracles(out.permute(0, 3, 1, 2).cpu(), src, M, frac_within=0.99)
     plain = warp(src.cuda(), M, (120, 360), channels_last_out=True)
-    assert seen[-1] == ("forward", 1)
-    assert (out - plain).abs().max().item() < 2e-6                  # same weights, possibly another fma contraction
-    assert torch.equal(out == 0, plain == 0)
+    assert seen[-1] == ("forward", 3)                               # NCHW source: tiled transpose + the channel-last kernel
+    assert torch.equal(out, plain)
+    # ... and its gradient comes back in the caller's NCHW layout, equal to the channel-last call's
+    leaf = src.cuda().requires_grad_(True)
+    leaf_cl = src_cl.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+    go = torch.randn(7, 120, 360, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    (g1,) = torch.autograd.grad(warp(leaf, M, (120, 360), channels_last_out=True), leaf, go)
+    (g2,) = torch.autograd.grad(warp(leaf_cl, M, (120, 360), channels_last_out=True), leaf_cl, go)
+    assert g1.is_contiguous() and g1.shape == (7, 128, 90, 160)
+    assert (g1 - g2).abs().max().item() <= 1e-4 * (1 + g2.abs().max().item())      # (atomics: summation order)
     # an NCHW destination of a channel-last source goes through the copy (documented restriction)
     nchw = warp(src_cl, M, (120, 360))
     assert seen[-1] == ("forward", 0) and torch.equal(nchw, warp(src.cuda(), M, (120, 360)))
