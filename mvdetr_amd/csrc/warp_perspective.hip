@@ -301,6 +301,66 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_fwd_cl(
     }
 }
 
+// Channel-last source -> NCHW destination (the reference's output layout, mvdetr.py:194): the same item loop as
+// warp_fwd_cl, but the blended 16-byte chunks go to an LDS tile [pixel][channel] first and leave as whole 128-byte runs
+// of 32 destination pixels per (channel, row) -- written channel by channel from registers they would be 4-byte
+// stores 4*H*W bytes apart.  Destination tile = 2 rows x 32 columns; channels in groups of 128.
+constexpr int WARP_NC_TW = 32, WARP_NC_TH = 2, WARP_NC_CG = 128, WARP_NC_LD = WARP_NC_CG + 4;
+__global__ __launch_bounds__(WARP_CL_THREADS) void warp_fwd_cl_nchw(
+    const float *__restrict__ src, const float *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
+    int nearest, float *__restrict__ dst)
+{
+    __shared__ WarpTexel<float> tex[WARP_PIX];
+    __shared__ __attribute__((aligned(16))) float ot[WARP_PIX * WARP_NC_LD];
+    const int tx = (W + WARP_NC_TW - 1) / WARP_NC_TW, ty = (H + WARP_NC_TH - 1) / WARP_NC_TH;
+    const int b = blockIdx.x, n = b / (tx * ty), rem = b - n * tx * ty;
+    const int i0 = (rem / tx) * WARP_NC_TH, j0 = (rem % tx) * WARP_NC_TW;
+    if (threadIdx.x < WARP_PIX) {
+        const int i = i0 + threadIdx.x / WARP_NC_TW, j = j0 + threadIdx.x % WARP_NC_TW;
+        tex[threadIdx.x] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, i < H && j < W, nearest);
+    }
+    __syncthreads();
+    const float *view = src + (int64_t)n * h * w * C;
+    const int rowC = w * C;
+    const bool vec_ok = (W & 3) == 0;
+    for (int cg = 0; cg < C; cg += WARP_NC_CG) {
+        const int cn = min(WARP_NC_CG, C - cg), chunks = cn / 4;
+        for (int item = threadIdx.x; item < WARP_PIX * chunks; item += WARP_CL_THREADS) {
+            const int p = item / chunks, c = (item - p * chunks) * 4;
+            const WarpTexel<float> t = tex[p];
+            float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t.valid) {
+                const float *sp = view + (int64_t)t.o00 * C + cg + c;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 a = (t.valid & 1) ? *reinterpret_cast<const float4 *>(sp) : z;
+                const float4 bq = (t.valid & 2) ? *reinterpret_cast<const float4 *>(sp + C) : z;
+                const float4 cc = (t.valid & 4) ? *reinterpret_cast<const float4 *>(sp + rowC) : z;
+                const float4 d = (t.valid & 8) ? *reinterpret_cast<const float4 *>(sp + rowC + C) : z;
+                out.x = t.w00 * a.x + t.w01 * bq.x + t.w10 * cc.x + t.w11 * d.x;
+                out.y = t.w00 * a.y + t.w01 * bq.y + t.w10 * cc.y + t.w11 * d.y;
+                out.z = t.w00 * a.z + t.w01 * bq.z + t.w10 * cc.z + t.w11 * d.z;
+                out.w = t.w00 * a.w + t.w01 * bq.w + t.w10 * cc.w + t.w11 * d.w;
+            }
+            *reinterpret_cast<float4 *>(ot + p * WARP_NC_LD + c) = out;
+        }
+        __syncthreads();
+        // (channel, tile row) segments of 32 pixels = 128 bytes, 8 lanes x float4 each
+        for (int item = threadIdx.x; item < cn * WARP_NC_TH * 8; item += WARP_CL_THREADS) {
+            const int part = item & 7, seg = item >> 3, r = seg % WARP_NC_TH, c = seg / WARP_NC_TH;
+            const int i = i0 + r, j = j0 + part * 4;
+            if (i >= H || j >= W) continue;
+            const float *o = ot + (r * WARP_NC_TW + part * 4) * WARP_NC_LD + c;
+            float *dp = dst + (((int64_t)n * C + cg + c) * H + i) * W + j;
+            if (vec_ok && j + 4 <= W) {
+                *reinterpret_cast<float4 *>(dp) = make_float4(o[0], o[WARP_NC_LD], o[2 * WARP_NC_LD], o[3 * WARP_NC_LD]);
+            } else {
+                for (int k = 0; k < 4 && j + k < W; ++k) dp[k] = o[k * WARP_NC_LD];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
     const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
@@ -352,8 +412,20 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
         // channel-last source: implemented for channel-last destinations, whole 16-byte chunks per pixel and a
         // view that fits 32-bit element offsets
         constexpr int VEC = 16 / (int)sizeof(T);
-        if (!(nhwc & 1) || C % VEC || !aligned(a, 16) || !aligned(o, 16) || (int64_t)h * w * C > 0x7fffffffLL)
+        if (C % VEC || !aligned(a, 16) || !aligned(o, 16) || (int64_t)h * w * C > 0x7fffffffLL)
             return (int)hipErrorNotSupported;
+        if (!(nhwc & 1)) {
+            // channel-last source, NCHW destination: forward, fp32 only
+            if constexpr (sizeof(T) == 4) {
+                if (!backward) {
+                    const int64_t nb2 = (int64_t)N * ((H + WARP_NC_TH - 1) / WARP_NC_TH) * ((W + WARP_NC_TW - 1) / WARP_NC_TW);
+                    if (nb2 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+                    hipLaunchKernelGGL(warp_fwd_cl_nchw, dim3((unsigned)nb2), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+                    return (int)hipGetLastError();
+                }
+            }
+            return (int)hipErrorNotSupported;
+        }
         const int64_t nb = warp_grid(N, H, W, 1);
         if (nb > 0x7fffffffLL) return (int)hipErrorInvalidValue;
         if (!backward)

@@ -41,10 +41,12 @@ def _transpose(x, n, rows, cols):
 
 
 def _channel_last_source(src, channels_last_out):
-    """True when ``src`` ([N,C,h,w] shape) already lies in memory as [N,h,w,C] and the channel-last kernel
-    takes it: then the warp reads it in place instead of copying it to NCHW first."""
+    """True when ``src`` ([N,C,h,w] shape) already lies in memory as [N,h,w,C] and a channel-last kernel takes it
+    (NHWC destination: any float dtype; NCHW destination: float32): then the warp reads it in place instead of
+    copying it to NCHW first."""
     n, c, h, w = src.shape
-    return (channels_last_out and src.is_cuda and c > 1 and h * w > 1 and src.is_contiguous(memory_format=torch.channels_last)
+    return ((channels_last_out or src.dtype == torch.float32) and src.is_cuda and c > 1 and h * w > 1
+            and src.is_contiguous(memory_format=torch.channels_last)
             and not src.is_contiguous() and (c * src.element_size()) % 16 == 0 and src.data_ptr() % 16 == 0)
 
 
@@ -57,10 +59,11 @@ class WarpPerspectiveFunction(Function):
         _channel_last_source_flag = src_cl                         # the caller's own layout (the gradient's layout)
         if not src_cl:
             src = src.contiguous()
-            if (channels_last_out and src.is_cuda and c > 1 and h * w > 1 and (c * src.element_size()) % 16 == 0
-                    and h * w * c < 2 ** 31 and n <= 65535):
+            if (channels_last_out and src.is_cuda and c > 1 and h * w > 1
+                    and (c * src.element_size()) % 16 == 0 and h * w * c < 2 ** 31 and n <= 65535):
                 # an NCHW source for a channel-last destination: one tiled transpose (reads and writes in 256-byte runs)
-                # and the channel-last kernel, instead of the NCHW kernel's 4-byte gathers (92 -> ~65 us at Wildtrack size)
+                # and the channel-last kernel, instead of the NCHW kernel's 4-byte gathers (92 -> 56 us at Wildtrack
+                # size).  NCHW -> NCHW keeps the gather kernel (90 us): transpose + warp_fwd_cl_nchw measured 142 us.
                 src = _transpose(src, n, c, h * w)                 # memory is now [n, h, w, c]
                 src_cl = True
         layout = (DST_NHWC if channels_last_out else 0) | (SRC_NHWC if src_cl else 0) | (NEAREST if nearest else 0)
