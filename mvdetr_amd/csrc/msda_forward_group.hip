@@ -204,13 +204,17 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                         nra = nrb = make_float4(r.x, r.y, r.x, r.y);
                     }
                 };
-                load_cam(cam0);
+                // camera-split variants (3 waves per SIMD, 168 registers): no look-ahead, the other waves cover the load --
+                // the prefetch registers spilled (91 VGPRs at 16 cameras)
+                constexpr bool AHEAD = SPLIT == 1;
+                if (AHEAD) load_cam(cam0);
 #pragma unroll
                 for (int c = 0; c < NGA; ++c) {
                     if (c >= ncam) continue;                  // (wave-uniform)
+                    if (!AHEAD) load_cam(cam0 + c);
                     float4 la = na, lb = nb, wa = nw;
                     const float4 ra = nra, rb = nrb;
-                    if (c + 1 < ncam) load_cam(cam0 + c + 1);
+                    if (AHEAD && c + 1 < ncam) load_cam(cam0 + c + 1);
                     float xs[4], ys[4];
                     if constexpr (FUSED) {
                         // fold this level's logits into camera c's running softmax
