@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 7
+#define MVDETR_OPS_ABI_VERSION 8
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -49,6 +49,19 @@ int mvdetr_msda_forward_f64(void *stream, const double *value, const int64_t *sp
                             const int64_t *level_start_index, const double *sampling_loc,
                             const double *attn_weight, int batch, int spatial_size, int num_heads,
                             int channels, int num_levels, int num_query, int num_point, double *out);
+
+/* 16-bit storage variants of the forward (an extension: the reference dispatches float and double only,
+ * ms_deform_attn_cuda.cu:64, so under autocast its callers cast to fp32 around the op).  Tensors as above with
+ * IEEE binary16 (`_f16`) or bfloat16 (`_bf16`) elements passed as raw 16-bit words; every arithmetic step is fp32 and
+ * the result is rounded once (nearest-even) when stored.  Forward only; device pointers only. */
+int mvdetr_msda_forward_f16(void *stream, const uint16_t *value, const int64_t *spatial_shapes,
+                            const int64_t *level_start_index, const uint16_t *sampling_loc,
+                            const uint16_t *attn_weight, int batch, int spatial_size, int num_heads, int channels,
+                            int num_levels, int num_query, int num_point, uint16_t *out);
+int mvdetr_msda_forward_bf16(void *stream, const uint16_t *value, const int64_t *spatial_shapes,
+                             const int64_t *level_start_index, const uint16_t *sampling_loc,
+                             const uint16_t *attn_weight, int batch, int spatial_size, int num_heads, int channels,
+                             int num_levels, int num_query, int num_point, uint16_t *out);
 
 /* Fused forward for deformable-encoder calls: the arithmetic MSDeformAttn.forward wraps around the core
  * (multiview_detector/models/ops/modules/ms_deform_attn.py:100-107) happens inside the kernel, so the

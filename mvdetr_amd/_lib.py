@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
@@ -34,6 +34,8 @@ SIGNATURES = {
     "mvdetr_msda_set_forward_impl": ([_i], _i),
     "mvdetr_msda_forward_f32": (_MSDA_FWD, _i),
     "mvdetr_msda_forward_f64": (_MSDA_FWD, _i),
+    "mvdetr_msda_forward_f16": (_MSDA_FWD, _i),
+    "mvdetr_msda_forward_bf16": (_MSDA_FWD, _i),
     "mvdetr_msda_fused_supported": ([_i] * 7, _i),
     "mvdetr_msda_forward_fused_f32": (_MSDA_FUSED, _i),
     "mvdetr_msda_fused_levels_supported": ([_i] * 9, _i),
@@ -106,10 +108,14 @@ def current_stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
-def suffix(dtype) -> str:
+def suffix(dtype, half_ok=False) -> str:
     if dtype == torch.float32:
         return "f32"
     if dtype == torch.float64:
         return "f64"
+    if half_ok and dtype == torch.float16:
+        return "f16"
+    if half_ok and dtype == torch.bfloat16:
+        return "bf16"
     # AT_DISPATCH_FLOATING_TYPES in the reference: float and double only (ms_deform_attn_cuda.cu:64)
     raise RuntimeError(f'"mvdetr_ops" not implemented for \'{dtype}\'')

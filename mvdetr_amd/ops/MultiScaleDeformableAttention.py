@@ -60,7 +60,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
                           ("level_start_index", level_start_index), ("sampling_loc", sampling_loc),
                           ("attn_weight", attn_weight)], allow_host=True)
     B, S, M, D, L, Lq, P = _dims(value, spatial_shapes, sampling_loc, im2col_step)
-    sfx = _lib.suffix(value.dtype)
+    # float16 / bfloat16: device forward only (16-bit storage, fp32 arithmetic; include/mvdetr_ops.h)
+    sfx = _lib.suffix(value.dtype, half_ok=not host)
     if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
         raise RuntimeError("value, sampling_loc and attn_weight must have the same dtype")
     _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)

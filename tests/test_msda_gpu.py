@@ -890,3 +890,41 @@ def test_encoder_shape_sweep_forward_and_backward(ops, i, L, D, M, H, W, B, nois
         logit = torch.log(aw.clamp_min(1e-30))
         fused = MSDA.ms_deform_attn_forward_fused(*dev(value, shapes, lsi, r3, off, logit)).cpu().double()
         assert (fused - want).abs().max().item() < FP32_TOL
+
+
+# ---- 16-bit storage forward (an extension: the reference is float/double only, ms_deform_attn_cuda.cu:64) ---------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    (2, [(6, 4), (3, 2)], 2, 2, 2, 2),        # ops/test.py's shape
+    (1, [(30, 45)] * 3, 8, 32, 700, 4),       # D = 32: 16-byte accesses
+    (2, [(7, 9), (5, 3)], 4, 12, 33, 3),      # D % 8 != 0: 8-byte accesses
+    (1, [(5, 5)], 3, 5, 9, 2),                # odd D: scalar accesses
+])
+def test_forward_half_matches_fp32_oracle(ops, dtype, case):
+    """fp16 / bf16 tensors in, fp32 arithmetic, one rounding on the way out: against the fp32 oracle on the SAME
+    (already rounded) inputs the only differences are accumulation order and that last rounding -- half an ulp of the
+    storage type (2^-11 / 2^-8 relative) plus the fp32 bar."""
+    _, MSDA = ops
+    B, hw, M, D, Lq, P = case
+    v, s, lsi, loc, aw = random_msda_inputs(B, hw, M, D, Lq, P, seed=11)
+    v, loc, aw = v.to(dtype), loc.to(dtype), aw.to(dtype)
+    out = MSDA.ms_deform_attn_forward(*dev(v, s, lsi, loc, aw), 64).cpu()
+    assert out.dtype == dtype and out.shape == (B, Lq, M * D)
+    ref = c_oracle.msda_forward(v.float(), s, lsi, loc.float(), aw.float())
+    ulp = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
+    err = (out.float() - ref).abs()
+    assert (err <= ulp * ref.abs() + FP32_TOL).all(), err.max().item()
+    # and the rounding is to nearest: the result equals the oracle's output rounded the same way almost everywhere
+    same = (out == ref.to(dtype)).float().mean().item()
+    assert same > 0.99, same
+
+
+def test_half_backward_is_refused(ops):
+    _, MSDA = ops
+    v, s, lsi, loc, aw = random_msda_inputs(1, [(4, 4)], 2, 4, 3, 2, seed=1)
+    args = dev(v.half(), s, lsi, loc.half(), aw.half())
+    go = torch.zeros(1, 3, 8, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError, match="not implemented"):
+        MSDA.ms_deform_attn_backward(*args, go, 64)
+    with pytest.raises(RuntimeError, match="not implemented"):        # the host path is float/double only
+        MSDA.ms_deform_attn_forward(v.half(), s, lsi, loc.half(), aw.half(), 64)
