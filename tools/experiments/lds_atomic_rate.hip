@@ -34,6 +34,24 @@ __global__ __launch_bounds__(256) void k(float *out, const int *tok, int iters)
             } else if (MODE == 8) {         // 32-bit integer atomics, consecutive dwords
                 a = ((it * 8 + u) * 64 + lane) & 16383;
                 __hip_atomic_fetch_add(reinterpret_cast<int *>(&win[a]), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (MODE == 9 || MODE == 10 || MODE == 11 || MODE == 12) {
+                // the production pattern: lanes = 2 rows of 32 cells (row stride 44 tokens), each cell's tap displaced
+                // by a few tokens (hash of lane / iteration), one channel plane per instruction
+                unsigned hsh = (lane * 2654435761u) ^ ((it * 8 + u) * 40503u);
+                hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
+                int jx = (int)(hsh % 7) - 3, jy = (int)((hsh >> 8) % 5) - 2;
+                if (MODE == 12) { jx = jx > 100 ? 1 : 0; jy = jy > 100 ? 1 : 0; }     // same VALU work, no displacement
+                const int tokn = (6 + (lane >> 5) + jy) * 44 + 6 + (lane & 31) + jx;
+                if (MODE == 9 || MODE == 12) {
+                    a = ((u & 15) * 708 + tokn) & 16383;
+                    __hip_atomic_fetch_add(reinterpret_cast<int *>(&win[a]), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (MODE == 10) {
+                    a = ((u & 7) * 708 + tokn) & 8191;
+                    __hip_atomic_fetch_add(&win64[a], (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    a = ((u & 15) * 708 + (6 + (lane >> 5)) * 44 + 6 + (lane & 31)) & 16383;     // no displacement
+                    __hip_atomic_fetch_add(reinterpret_cast<int *>(&win[a]), (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             } else if (MODE == 3) {            // read-modify-write without atomics, same addresses as MODE 1
                 a = ((r * 32) + (lane & 15) + ((lane >> 4) & 1) * 16) & 16383;
                 win[a] += v;
@@ -85,5 +103,9 @@ int main()
     run<6>("ds_add_u64 lanes = random tokens", d_out, d_tok);
     run<7>("ds_add_u64 consecutive qwords", d_out, d_tok);
     run<8>("ds_add_u32 consecutive dwords", d_out, d_tok);
+    run<11>("ds_add_u32 2 rows x 32 cells, undisplaced", d_out, d_tok);
+    run<9>("ds_add_u32 2 rows x 32 cells, +-3 x +-2 px", d_out, d_tok);
+    run<12>("ds_add_u32 2 rows x 32, hash computed, undisplaced", d_out, d_tok);
+    run<10>("ds_add_u64 2 rows x 32 cells, +-3 x +-2 px", d_out, d_tok);
     return 0;
 }
