@@ -11,7 +11,7 @@
 // and stores them as one contiguous run: a camera-grouped variant (one staged window for all cameras' queries,
 // results stored level by level) measured 590 us against 190 us for the forward of the same structure --
 // 16/32-byte pieces 112/224 bytes apart are partial-line writes, which ECC memory turns into read-modify-writes.  Taps outside the
-// window read global memory.  Levels of unequal shape are detected on the device: msda_bwd_value_tile
+// window read global memory.  Levels of unequal shape are detected on the device: msda_bwd_value_win
 // (msda_backward_tile.hip, always launched first) then computes all three gradients and this kernel returns.
 //
 // Replaces (with msda_backward.hip / msda_backward_tile.hip) the grad_sampling_loc / grad_attn_weight half of
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
     if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
-    if (!equal) return;          // msda_bwd_value_tile has done all three gradients for such calls
+    if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
 
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
