@@ -11,10 +11,10 @@ O=$R/gpurun_out/profile_$TAG
 mkdir -p $O
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-gemm-tuning $@"   # (tuning would fill the trace with candidate GEMMs)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench.py $ARGS > $O/bench_under_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $O/pmc_fetch -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $O/pmc_write -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_write.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_sq -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench.py $ARGS > $O/bench_under_trace.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $O/pmc_fetch -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $O/pmc_write -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_sq -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_sq.log 2>&1
 cd $R
 python tools/rocpd_summary.py $O/trace/t_results.db > $O/${TAG}_kernel_stats.txt
 python tools/rocpd_summary.py $O/pmc_fetch/p_results.db --filter mvdetr > $O/${TAG}_pmc_fetch.txt

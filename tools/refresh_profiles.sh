@@ -8,9 +8,9 @@ cat $O/${TAG}_bench.json
 bash tools/profile_bench.sh $TAG > $O/profile_bench.log 2>&1
 (python tools/microbench.py --iters 30; python tools/microbench.py --iters 10 --config multiviewx; python tools/microbench.py --iters 5 --config stress16) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_microbench.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $O/mb_trace -o t -- python $R/tools/microbench.py --iters 10 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/mb_fetch -o p -- python $R/tools/microbench.py --iters 3 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/mb_write -o p -- python $R/tools/microbench.py --iters 3 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $O/mb_trace -o t -- python $R/tools/microbench.py --iters 10 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/mb_fetch -o p -- python $R/tools/microbench.py --iters 3 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/mb_write -o p -- python $R/tools/microbench.py --iters 3 > /dev/null 2>&1
 cd $R; python tools/rocpd_summary.py $O/mb_trace/t_results.db --filter mvdetr > $O/${TAG}_microbench_kernel_stats.txt
 # HBM-side bytes of every kernel of the microbenchmark (forward / backward / warp), separate --pmc passes;
 # FETCH_SIZE is KB and reports half the bytes of 16-byte-per-lane reads on gfx950 (see ${TAG}_traffic.json)
