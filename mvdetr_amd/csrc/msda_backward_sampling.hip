@@ -19,6 +19,20 @@
 #include "common.h"
 #include "msda_dispatch.h"
 #include "msda_tile.h"
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef MVDETR_BWD_TRACE
+// tuning aid (never in the shipped build): 100 MHz wall-clock stamps of one workgroup's waves
+__device__ unsigned long long g_bws_trace[2048];
+extern "C" int mvdetr_debug_bws_trace(unsigned long long *host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bws_trace), n * sizeof(unsigned long long));
+}
+#define STRACE(i) do { if (blockIdx.x == 8 && (threadIdx.x & 63) == 0 && (i) < 2048) g_bws_trace[(i)] = wall_clock64(); } while (0)
+#else
+#define STRACE(i) do { } while (0)
+#endif
 
 namespace mvdetr {
 
@@ -31,6 +45,11 @@ __device__ __forceinline__ f2 dot4(const float4 &a, const float4 &b, f2 acc)
     return __builtin_elementwise_fma((f2){a.z, a.w}, (f2){b.z, b.w}, acc);
 }
 __device__ __forceinline__ float hsum(f2 v) { return v.x + v.y; }
+// the value of lane ^ 1 (DPP quad_perm [1,0,3,2]; __shfl_xor goes through ds_bpermute_b32, i.e. the LDS queue)
+__device__ __forceinline__ float neighbour(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
 
 // d = <g, corner> for the four corners of the tap at pixel position (x, y) of a level, corners read from
 // global memory with zero padding; NV float4 chunks per lane, chunk k of `g` holds channels 4*(k^rot)..+3
@@ -44,6 +63,23 @@ __device__ __forceinline__ void corners_from_memory(const float *__restrict__ vl
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         const int ko = (k ^ rot) << 2;
+        if (f.vy0 && f.vx0) d00 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + ko), d00);
+        if (f.vy0 && f.vx1) d01 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + row + ko), d01);
+        if (f.vy1 && f.vx0) d10 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + ko), d10);
+        if (f.vy1 && f.vx1) d11 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + row + ko), d11);
+    }
+}
+
+// the same for a lane holding TWO chunks: chunk k of `g` is channels 4*((first + k)^rot)..+3
+__device__ __forceinline__ void corners_from_memory_half(const float *__restrict__ vlevel, int64_t row, int H, int W, float x,
+                                                         float y, int first, int rot, const float4 *g, f2 &d00, f2 &d01,
+                                                         f2 &d10, f2 &d11)
+{
+    const Footprint<float> f = footprint(y, x, H, W);
+    const float *r0 = vlevel + ((int64_t)f.y0 * W + f.x0) * row, *r1 = r0 + (int64_t)W * row;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int ko = ((first + k) ^ rot) << 2;
         if (f.vy0 && f.vx0) d00 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + ko), d00);
         if (f.vy0 && f.vx1) d01 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + row + ko), d01);
         if (f.vy1 && f.vx0) d10 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + ko), d10);
@@ -160,7 +196,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
                         q10 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * SLICE), q10);
                         q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * SLICE + SLICE), q11);
                     }
-                } else if (y > -1.f && x > -1.f && y < fH && x < fW) {
+                } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {       // (lanes without a cell carry cell 0's taps)
                     corners_from_memory<NV>(vbatch + lsi[l] * row + lane_off, row, Hq, Wq, x, y, rot, g, q00, q01, q10, q11);
                 }
                 float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
@@ -193,6 +229,176 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
     }
 }
 
+// ---- all source windows resident: D = 16, L <= 7 (MVDeTr's own shapes) ------------------------------------------------
+// msda_bwd_sampling_tile stages the L source windows once per QUERY level: 7 x 7 windows of 72 KB per 128 cells,
+// 1.35 GB of L2->LDS copies per launch at Wildtrack size, most of them L2 misses (FETCH_SIZE 1.18 GB) -- and between two
+// barriers per window it has 4 taps per lane to do.  Here a job is (4 x 8 cells, one head) and ALL L source windows of
+// that head (16 x 20 tokens x 64 B = 20 KB each) are staged by LDS-DMA before anything is read: one barrier per job,
+// 0.39 GB of copies per launch; a lane is one (camera, cell) -- every camera's query at that cell samples the same
+// windows -- so a (query, head)'s sampling data of all levels is ONE contiguous 336-byte run on the way in (no
+// 16/32-byte pieces per level) and its gradients one contiguous run on the way out.  One workgroup per CU (143 KB of
+// LDS at L = 7), 4 waves with up to 512 VGPRs each: the level loop is fully unrolled.
+constexpr int RS_TH = 4, RS_TW = 8, RS_R = 6, RS_WH = RS_TH + 2 * RS_R, RS_WW = RS_TW + 2 * RS_R, RS_NTOK = RS_WH * RS_WW;
+constexpr int RS_D = 16, RS_MAXL = 7, RS_THREADS = 512;
+static_assert(RS_NTOK % 16 == 0, "a DMA instruction covers 16 window positions");
+
+__global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
+    const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
+    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw, const int *__restrict__ local_hits)
+{
+    extern __shared__ __attribute__((aligned(16))) float vwin[];      // [L][RS_NTOK][16]
+    constexpr int D = RS_D, TH = RS_TH, TW = RS_TW, WH = RS_WH, WW = RS_WW, NTOK = RS_NTOK, P = TILE_P, NV = 2;
+    const int tid = threadIdx.x;
+    const int64_t row = (int64_t)M * D;
+
+    bool equal = true;
+    for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
+    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
+    if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
+
+    const int Hq = (int)shapes[0], Wq = (int)shapes[1];
+    const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
+    const int jobs = per_level * M * B, jobs8 = (jobs + 7) / 8;
+    const float fW = (float)Wq, fH = (float)Hq;
+
+    // lane = (camera, cell, half of the head's 16 channels): a wave is one camera's 32 cells; two waves per SIMD
+    const int sub = tid & 1, cam_raw = (tid >> 1) / (TH * TW), cam = cam_raw < L ? cam_raw : L - 1;
+    const int qi = (tid >> 1) % (TH * TW), qly = qi / TW, qlx = qi % TW;
+    // LDS bank spreading: lane reads chunks (2 * sub + k) ^ rot.  A bank row is 256 B = four 64-byte tokens, and a quarter
+    // wave (16 lanes x 16 B) is served in one pass if its lanes hit 16 different 16-byte slots: its lanes are 8 cells x
+    // 2 halves, cells 0-3 cover the four tokens of a bank row with two chunks each, cells 4-7 take the other two
+    const int rot = (qlx >> 2) & 1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    // window copy: an instruction moves 16 consecutive window positions x 4 chunks of 16 bytes
+    const int my_pos = lane >> 2, my_chunk = lane & 3;
+
+    for (int t = blockIdx.x; t < jobs8 * 8; t += gridDim.x) {
+        const int job = (t & 7) * jobs8 + (t >> 3);          // XCD k takes a contiguous band of jobs
+        if ((t >> 3) >= jobs8 || job >= jobs) continue;
+        const int head = job % M, u2 = job / M;               // the heads of a tile run back to back: same token rows
+        const int tin = u2 % per_level, b = u2 / per_level;
+        const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
+        const int qy = Y0 + qly, qx = X0 + qlx;
+        const bool active = qy < Hq && qx < Wq && cam_raw < L;
+        const int64_t q = (int64_t)b * S + lsi[cam] + (active ? (int64_t)qy * Wq + qx : 0);
+        const int64_t e0 = (q * M + head) * L * P;            // this (query, head)'s first tap
+        const float *vbatch = value + (int64_t)b * S * row + head * D;
+        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+        const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
+
+        [[maybe_unused]] const int tr = ((t - (int)blockIdx.x) / (int)gridDim.x) * 128 + (tid >> 6) * 16;
+        STRACE(tr + 0);
+        __syncthreads();                                      // everyone is done reading the previous job's windows
+        STRACE(tr + 1);
+        {
+            const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(vbatch), 0, (int)((unsigned)S * (unsigned)row * 4u - (unsigned)(head * D) * 4u), 0x00020000);
+            // a wave takes window positions [16 k, 16 k + 16) for k = wave, wave + 8, ... of every level: one address
+            // computation per k, one instruction per (k, level)
+            for (int k = wave_u; k < NTOK / 16; k += RS_THREADS / 64) {
+                const int wp = k * 16 + my_pos, wy = wp / WW, wx = wp % WW, gy = oy + wy, gx = ox + wx;
+                const unsigned vo = ((unsigned)gx < (unsigned)Wq && (unsigned)gy < (unsigned)Hq)
+                                        ? (unsigned)((gy * Wq + gx) * (int)row + my_chunk * 4) * 4u : 0x80000000u;
+                for (int l = 0; l < L; ++l) {
+                    const unsigned so = (unsigned)((int)lsi[l] * (int)row) * 4u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(vwin + (l * NTOK + k * 16) * D),
+                                                             16, (int)vo, (int)so, 0, 0);
+                }
+            }
+        }
+        STRACE(tr + 2);
+        float4 g[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const float4 *>(go + q * row + head * D + (((2 * sub + k) ^ rot) << 2));
+        // the (query, head)'s sampling data of all levels: one contiguous run each
+        float4 la[RS_MAXL], lb[RS_MAXL], wa[RS_MAXL];
+#pragma unroll
+        for (int l = 0; l < RS_MAXL; ++l) {
+            const int ll = l < L ? l : L - 1;
+            la[l] = *reinterpret_cast<const float4 *>(loc + (e0 + ll * P) * 2);
+            lb[l] = *reinterpret_cast<const float4 *>(loc + (e0 + ll * P) * 2 + 4);
+            wa[l] = *reinterpret_cast<const float4 *>(aw + e0 + ll * P);
+        }
+        STRACE(tr + 3);
+        __syncthreads();                                      // the windows have landed
+        STRACE(tr + 4);
+
+        float4 r_aw[RS_MAXL], r_l0[RS_MAXL], r_l1[RS_MAXL];
+#pragma unroll
+        for (int l = 0; l < RS_MAXL; ++l) {
+            if (l >= L) continue;                             // (uniform; `break` would keep the loop from unrolling)
+            const float *wl = vwin + l * NTOK * D;
+            const float xs[4] = {la[l].x * fW - 0.5f, la[l].z * fW - 0.5f, lb[l].x * fW - 0.5f, lb[l].z * fW - 0.5f};
+            const float ys[4] = {la[l].y * fH - 0.5f, la[l].w * fH - 0.5f, lb[l].y * fH - 0.5f, lb[l].w * fH - 0.5f};
+            const float as[4] = {wa[l].x, wa[l].y, wa[l].z, wa[l].w};
+            float ga[4], gx[4], gy[4];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float x = xs[p], y = ys[p];
+                f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
+                if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
+                    const int ix = (int)floorf(x) - ox, iy = (int)floorf(y) - oy;
+                    const float *p00 = wl + (iy * WW + ix) * D;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        const float *pk = p00 + (((2 * sub + k) ^ rot) << 2);
+                        q00 = dot4(g[k], *reinterpret_cast<const float4 *>(pk), q00);
+                        q01 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + D), q01);
+                        q10 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D), q10);
+                        q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D + D), q11);
+                    }
+                } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {       // (lanes without a cell carry cell 0's taps)
+                    corners_from_memory_half(vbatch + lsi[l] * row, row, Hq, Wq, x, y, 2 * sub, rot, g, q00, q01, q10, q11);
+                }
+                float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+                d00 += neighbour(d00);                        // the other half of the head sits in the neighbouring lane
+                d01 += neighbour(d01);
+                d10 += neighbour(d10);
+                d11 += neighbour(d11);
+                const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
+                ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
+                gx[p] = in_image ? fW * as[p] * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+                gy[p] = in_image ? fH * as[p] * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                __builtin_amdgcn_sched_barrier(0);            // one tap's 16 LDS reads in flight at a time
+            }
+            r_aw[l] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+            r_l0[l] = make_float4(gx[0], gy[0], gx[1], gy[1]);
+            r_l1[l] = make_float4(gx[2], gy[2], gx[3], gy[3]);
+        }
+        STRACE(tr + 5);
+        if (active && sub == 0) {
+#pragma unroll
+            for (int l = 0; l < RS_MAXL; ++l) {
+                if (l >= L) continue;
+                *reinterpret_cast<float4 *>(grad_aw + e0 + l * P) = r_aw[l];
+                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2) = r_l0[l];
+                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2 + 4) = r_l1[l];
+            }
+        }
+    }
+}
+
+static int launch_sampling_resident(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                    const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
+                                    float *grad_loc, float *grad_aw, const int *local_hits)
+{
+    const int lds = L * RS_NTOK * RS_D * 4;
+    static int blocks = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_resident),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, RS_MAXL * RS_NTOK * RS_D * 4);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        return (cus + 7) / 8 * 8;                             // one workgroup per CU (LDS)
+    }();
+    hipLaunchKernelGGL(msda_bwd_sampling_resident, dim3((unsigned)blocks), dim3(RS_THREADS), lds, st, go, value, shapes, lsi,
+                       loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits);
+    return (int)hipGetLastError();
+}
+
 using SWide16 = TileCfg<16, 32, 8, 16, 6>;
 using SWide32 = TileCfg<32, 32, 8, 16, 6>;
 
@@ -223,6 +429,8 @@ int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *va
                                 float *grad_loc, float *grad_aw, const int *local_hits)
 {
 #define SAMPLING_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits
+    static const bool resident_ok = [] { const char *e = getenv("MVDETR_MSDA_BWD_SAMPLING"); return !(e && !strcmp(e, "tile")); }();
+    if (resident_ok && D == RS_D && L <= RS_MAXL && (int64_t)S * M * D * 4 < 0x7fffffffLL) return launch_sampling_resident(SAMPLING_ARGS);
     if (D == 16) return L <= 8 ? launch_sampling_tile<SWide16, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide16, 16>(SAMPLING_ARGS);
     if (D == 32) return L <= 8 ? launch_sampling_tile<SWide32, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide32, 16>(SAMPLING_ARGS);
     return (int)hipErrorInvalidValue;
