@@ -189,8 +189,10 @@ def test_misuse_raises_like_reference(ops):
         MSDA.ms_deform_attn_forward(value, shapes, lsi, loc.transpose(1, 2).contiguous().transpose(1, 2), aw, 3)
     with pytest.raises(RuntimeError, match="spatial_shapes must be a CUDA tensor"):
         MSDA.ms_deform_attn_forward(value, shapes.cpu(), lsi, loc, aw, 3)
-    with pytest.raises(RuntimeError, match="not implemented for"):
-        MSDA.ms_deform_attn_forward(value.half(), shapes, lsi, loc.half(), aw.half(), 3)
+    with pytest.raises(RuntimeError, match="not implemented for"):       # AT_DISPATCH_FLOATING_TYPES, cu:64 (the forward takes
+        MSDA.ms_deform_attn_forward(value.to(torch.int32), shapes, lsi, loc, aw, 3)   # fp16/bf16 here: an extension, tested below)
+    with pytest.raises(RuntimeError, match="same dtype"):
+        MSDA.ms_deform_attn_forward(value.half(), shapes, lsi, loc, aw, 3)
 
 
 def test_inputs_are_not_mutated_and_stream_is_respected(ops):

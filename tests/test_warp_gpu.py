@@ -106,7 +106,8 @@ def test_channels_last_output_equals_permuted(warp):
     Ms = torch.diag(torch.tensor([0.1, 0.1, 1.0])) @ Ms
     a = warp(src, Ms, (9, 21))
     b = warp(src, Ms, (9, 21), channels_last_out=True)
-    assert torch.equal(a.permute(0, 2, 3, 1), b)
+    assert (a.permute(0, 2, 3, 1) - b).abs().max().item() < 2e-6   # (two template instances: fma contraction may differ)
+    assert torch.equal(a.permute(0, 2, 3, 1) == 0, b == 0)
     ref = c_oracle.warp_perspective(src.cpu().double(), Ms.double(), (9, 21))
     assert (a.cpu().double() - ref).abs().max().item() < 1e-5
 
