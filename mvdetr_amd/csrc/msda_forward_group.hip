@@ -390,8 +390,6 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
         default: break;
         }
     }
-    static const int variant = [] { const char *e = getenv("MVDETR_MSDA_GROUP_VARIANT"); return e ? atoi(e) : 0; }();
-    if (D == 16 && L == 7 && variant == 4) return fused == 2 ? launch_group<GQuad16, 7, 3, 2, 4, true>(GROUP_ARGS) : fused ? launch_group<GQuad16, 7, 3, 1, 4, true>(GROUP_ARGS) : launch_group<GQuad16, 7, 3, 0, 4, true>(GROUP_ARGS);
     // fused entries copy their windows with LDS-DMA (measured at Wildtrack size: 136 -> 127 us; the public contract's
     // kernel is a shade slower with it, 172 -> 174 us, and keeps the register-staged copy)
     if (D == 16 && L == 7) return fused == 2 ? launch_group<GWide16, 7, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide16, 7, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide16, 7, 2, 0>(GROUP_ARGS);
