@@ -81,8 +81,9 @@ def test_view_sharded_all_gather_world2(num_views):
 
 
 # ---- query-sharded encoder ---------------------------------------------------
-# The product's attention core is the HIP extension and has no CPU form; for these CPU tests of the
-# *communication schedule* the extension's forward entry is replaced by the oracle (test infrastructure).
+# On the CPU the attention core is the library's own host path (csrc/host_path.cpp), i.e. these tests run the product
+# end to end; `core="oracle"` swaps the extension's forward entry for the oracle (test infrastructure) as a cross-check
+# of the schedule that is independent of the library.
 
 def _oracle_core_patch(monkeypatch=None):
     """monkeypatch=None only inside a spawned worker process (nothing to restore there)."""
@@ -112,10 +113,12 @@ def _small_world_feat(num_views, C=16, H=8, W=12, seed=0):
     return wf.eval(), h, w
 
 
+@pytest.mark.parametrize("core", ["host", "oracle"])
 @pytest.mark.parametrize("num_views,world", [(7, 3), (7, 8), (6, 4), (3, 1), (16, 8)])
-def test_query_sharded_fusion_lockstep(num_views, world, monkeypatch):
+def test_query_sharded_fusion_lockstep(num_views, world, core, monkeypatch):
     """Emulated ranks in one process: per-layer value exchange + partial merge == unsharded fuse()."""
-    _oracle_core_patch(monkeypatch)
+    if core == "oracle":
+        _oracle_core_patch(monkeypatch)
     wf, h, w = _small_world_feat(num_views)
     B, C = 2, wf.hidden_dim
     tokens = torch.randn(B, num_views * h * w, C, generator=torch.Generator().manual_seed(9))
@@ -135,10 +138,9 @@ def test_query_sharded_fusion_lockstep(num_views, world, monkeypatch):
 
 def _sharded_worker(rank, world, port, num_views, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
+                      LOCAL_RANK=str(rank), MVDETR_HOST_THREADS="2")
     try:
-        mdist.init_from_env()
-        _oracle_core_patch()
+        mdist.init_from_env()                 # (the attention core is the library's host path: nothing is patched)
         wf, h, w = _small_world_feat(num_views)
         B, C = 2, wf.hidden_dim
         tokens = torch.randn(B, num_views * h * w, C, generator=torch.Generator().manual_seed(9))
