@@ -1,8 +1,9 @@
 """ctypes binding of libmvdetr_ops.so (C ABI in include/mvdetr_ops.h).
 
 There is NO fallback: if the shared library is missing or does not export the expected symbols
-the import of the op layer raises, and calling an op with CPU tensors raises like the reference
-extension does (ms_deform_attn.h:38 "Not implemented on the CPU").
+the import of the op layer raises.  GPU tensors only ever reach the HIP kernels; calls whose tensors are ALL on
+the CPU run the same library's own host path (csrc/host_path.cpp -- where the reference extension raises
+"Not implemented on the CPU", ms_deform_attn.h:38); mixed devices raise.
 """
 from __future__ import annotations
 
