@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 8
+#define MVDETR_OPS_ABI_VERSION 9
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -160,7 +160,13 @@ int mvdetr_warp_perspective_forward_f64(void *stream, const double *src, const d
 /* Gradient of the warp w.r.t. src (what autograd reaches through grid_sample in the reference).
  *   grad_dst [n, channels, dst_h, dst_w] (or NHWC if layout_nhwc bit 0)
  *   grad_src [n, channels, src_h, src_w] (or NHWC if layout_nhwc bit 1, same restrictions as the forward);
- *            MUST BE ZERO on entry (accumulated with atomics)
+ *            OVERWRITTEN: every element is stored, it need not be zeroed (ABI 9; up to ABI 8 it had to be zero on entry)
+ * With both sides channel-last (layout_nhwc & 3 == 3) the gradient is computed as a GATHER over the destination pixels
+ * whose bilinear footprint touches each source texel (the homography is invertible): no atomics, the order of every
+ * sum is fixed, so the result is deterministic -- unlike grid_sample's atomicAdd backward.  It allocates
+ * 32 bytes per 2x2 block of source texels of stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`).
+ * The other layouts scatter with fp atomics after a hipMemsetAsync (MVDETR_WARP_BWD_IMPL=scatter forces that for
+ * channel-last tensors too).
  */
 int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, const float *M, int n,
                                          int channels, int src_h, int src_w, int dst_h, int dst_w,
@@ -192,6 +198,10 @@ int mvdetr_add_layernorm_add_f32(void *stream, const float *x, const float *resi
 const char *mvdetr_msda_last_forward_impl(void);
 /* Name of the kernel that call launched ("msda_fwd_group[LDS-DMA windows]", "msda_fwd_tile", "msda_fwd_gather", ...). */
 const char *mvdetr_msda_last_forward_kernel(void);
+
+/* Name of the kernel the last warp call of this process launched (any thread: autograd runs backwards on its own) ("warp_fwd_cl", "warp_fwd<NCHW>", "warp_bwd_gather",
+ * ...): one name per layout route, asserted by tests/test_warp_gpu.py.  Static storage; never NULL. */
+const char *mvdetr_warp_last_kernel(void);
 
 /* Forward kernel variant selection: 0 = auto (default; tiled LDS kernel where it applies, else
  * the gather kernel), 1 = always gather, 2 = tile whenever the shape supports it.  Results are

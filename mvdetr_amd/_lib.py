@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
@@ -33,6 +33,7 @@ SIGNATURES = {
     "mvdetr_msda_last_forward_impl": ([], ctypes.c_char_p),
     "mvdetr_msda_last_forward_kernel": ([], ctypes.c_char_p),
     "mvdetr_msda_set_forward_impl": ([_i], _i),
+    "mvdetr_warp_last_kernel": ([], ctypes.c_char_p),
     "mvdetr_msda_forward_f32": (_MSDA_FWD, _i),
     "mvdetr_msda_forward_f64": (_MSDA_FWD, _i),
     "mvdetr_msda_forward_f16": (_MSDA_FWD, _i),

@@ -17,6 +17,9 @@
 // transposed through LDS (65-float rows, conflict-free both ways) so the stores are 256-byte rows.
 #include "common.h"
 #include "../../include/mvdetr_ops.h"
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 
 namespace mvdetr {
 
@@ -396,115 +399,524 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
     }
 }
 
-// ---- NCHW source -> NCHW destination through LDS source patches (fp32) -------------------------------------------
-// The gather kernel above issues one 8-byte gather per (pixel, channel, corner row) -- 10 M wave-level gathers at
-// Wildtrack size, each touching a dozen cache lines -- and stores 32-byte row pieces (8x8 tiles): it runs at the
-// texture-address rate (90 us, 28 % of the roofline).  The destination grid is ~3x denser than the source, so here a
-// workgroup owns an 8 x 32 destination tile (lanes = pixels, x fastest: 128-byte store runs), finds the bounding box
-// of the tile's source footprints (a compact patch: a few hundred texels), and per chunk of channels copies the
-// patch rows to LDS with coalesced row loads (texels outside the image are stored as zeros: zero padding needs no
-// per-corner test afterwards), then every lane blends its four corners from LDS (two ds_read2_b32).  The channel
-// chunk adapts to the patch: WARP_PATCH_FLOATS / patch texels, at most 8; a patch that does not fit at all (extreme
-// magnification) takes per-lane gathers for that tile.
-constexpr int WARP_P_TH = 8, WARP_P_TW = 32, WARP_PATCH_FLOATS = 8192, WARP_P_CC = 8;
+// ---- backward as a GATHER (channel-last on both sides; no atomics, deterministic) ------------------------------------
+// grid_sample's backward scatters: every destination pixel adds w_k * grad to the four source texels of its bilinear
+// footprint (warp_bwd / warp_bwd_cl above: one memory-side atomic request per contiguous segment, 382 us at Wildtrack
+// size, 6.8 % of the roofline).  The homography is invertible, so the sum can be turned around: the destination pixels
+// whose footprint touches a 2 x 2 BLOCK of source texels are those whose source position lies in
+// [2bx-1, 2bx+2) x [2by-1, 2by+2), and that set is the image of this square under M (dst <- src) -- a convex
+// quadrilateral of a few dozen pixels (a few hundred for the far field, where the ground plane is magnified).
+//   * warp_bwd_gather: a group of G = C/4 lanes (32 at 128 channels; two groups per wave) owns one block.
+//     1. Candidate scan: when the square does not cross the line that maps to infinity (the horizon: same sign of the
+//        homogeneous coordinate at all four corners) its image is the hull of the four projected corners.  Far-field
+//        images are long diagonal slivers whose bounding box is ~10x their area, so the scan is a SHEARED box: lines
+//        (rows or columns, whichever is cheaper) u0..u1, and on line u the `len` pixels from ceil(a + s (u - uc)) on,
+//        with the shear s taken from one of the hull's edges (the cheapest of five candidates).  Squares that do cross
+//        the horizon get plain boxes from clipping the destination rectangle (Sutherland-Hodgman, one lane, LDS)
+//        against the five linear inequalities "source position inside the square", once per sign of the homogeneous
+//        coordinate.  Scans are only candidate sets: membership is decided by the exact test below.
+//     2. The G lanes test G candidates at a time with the forward's own source_position / make_coord (forward and
+//        backward use the same weights bit for bit), compact the hits in scan order into LDS (ballot + popcount: the
+//        order of every sum is fixed -> deterministic results), then every lane walks the hits, loads its 16-byte
+//        channel chunk of grad_dst (the group reads whole 512-byte pixel rows) and accumulates into the block's four
+//        texels in registers.
+//     grad_src is written once, with plain stores: it need not be zeroed, and each grad_dst row is read ~2.25 times
+//     (once per block its footprint touches), mostly from L2.
+//   * warp_bwd_stragglers: kornia divides by z only where |z| > 1e-8 (convert_points_from_homogeneous); a destination
+//     pixel with |z| <= 1e-8 samples a position unrelated to the projective map, so no scan finds it.  The gather skips
+//     such pixels and this kernel (one lane per destination pixel, returns at once unless |z| <= 1e-8) scatters them
+//     with atomics afterwards -- normally nothing.
+template <typename T> struct WarpRec {
+    int pix;                     // destination pixel index (n * H + i) * W + j
+    int mask;                    // bit t: the footprint touches block texel t = 2 * (Y - 2by) + (X - 2bx)
+    T w[4];                      // its weight there (the forward's T(wy * wx))
+};
 
-__global__ __launch_bounds__(256) void warp_fwd_nchw_patch(
-    const float *__restrict__ src, const float *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
-    int nearest, float *__restrict__ dst)
+struct WarpScan {
+    int u0, u1;                  // lines u0..u1 (inclusive); empty when u1 < u0
+    int len;                     // candidates per line
+    int swap;                    // 0: lines are destination rows (u = i, v = j); 1: lines are columns (u = j, v = i)
+    double a, s, uc;             // line u starts at v = ceil(a + s * (u - uc))
+};
+
+// homogeneous coordinate of destination pixel (i, j) under M^-1 (the pz of source_position): the forward divides by it
+// only where |pz| > 1e-8
+template <typename T> __device__ __forceinline__ double source_pz(const T *__restrict__ Mn, int i, int j)
 {
-    __shared__ float patch[WARP_PATCH_FLOATS];
-    __shared__ int box[4][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx = (W + WARP_P_TW - 1) / WARP_P_TW, ty = (H + WARP_P_TH - 1) / WARP_P_TH;
-    int r = blockIdx.x;
-    const int j0 = (r % tx) * WARP_P_TW;
-    r /= tx;
-    const int i0 = (r % ty) * WARP_P_TH, n = r / ty;
-    const int i = i0 + tid / WARP_P_TW, j = j0 + tid % WARP_P_TW;
-    const bool live = i < H && j < W;
-    SrcCoord sc;
-    sc.any = false;
-    sc.x0 = sc.y0 = 0;
-    if (live) {
-        double x, y;
-        source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
-        sc = make_coord(x, y, h, w, nearest);
-    }
-    const bool use = live && sc.any;
-    float w00 = use && sc.v00 ? (float)(sc.wy0 * sc.wx0) : 0.f, w01 = use && sc.v01 ? (float)(sc.wy0 * sc.wx1) : 0.f;
-    float w10 = use && sc.v10 ? (float)(sc.wy1 * sc.wx0) : 0.f, w11 = use && sc.v11 ? (float)(sc.wy1 * sc.wx1) : 0.f;
+    const double m0 = Mn[0], m1 = Mn[1], m2 = Mn[2], m3 = Mn[3], m4 = Mn[4], m5 = Mn[5], m6 = Mn[6],
+                 m7 = Mn[7], m8 = Mn[8];
+    const double c0 = m4 * m8 - m5 * m7, c1 = m5 * m6 - m3 * m8, c2 = m3 * m7 - m4 * m6;
+    const double r = 1.0 / (m0 * c0 + m1 * c1 + m2 * c2);
+    return (c2 * (double)j + (m1 * m6 - m0 * m7) * (double)i + (m0 * m4 - m1 * m3)) * r;
+}
 
-    // bounding box of the footprints [x0, x0+1] x [y0, y0+1] (x0 in [-1, w-1]: may stick out of the image by one)
-    int xmin = use ? sc.x0 : 0x3fffffff, xmax = use ? sc.x0 + 1 : -0x3fffffff;
-    int ymin = use ? sc.y0 : 0x3fffffff, ymax = use ? sc.y0 + 1 : -0x3fffffff;
+constexpr int WARP_CLIP_MAXV = 12;      // rectangle (4) + one new vertex per clip (5), rounded up
+constexpr int WARP_CLIP_SLOTS = 4 * WARP_CLIP_MAXV + 15;        // polygon double buffer + the 5 x 3 coefficients
+constexpr int WARP_SCAN_THREADS = 64;
+
+// bounding box of {(j, i) in [-1, W] x [-1, H] : e[k] . (j, i, 1) >= 0 for all k}; false when empty.  `lds` is this lane's
+// scratch, slot-major over the workgroup's lanes (slot s of lane l at lds[s * WARP_SCAN_THREADS]: conflict-free);
+// slots 0..4*MAXV-1 hold the polygon double buffer, the 15 coefficients follow.
+__device__ inline bool warp_clip_box(double *lds, int H, int W, int &i0, int &i1, int &j0, int &j1)
+{
+#define SLOT(k) lds[(k) * WARP_SCAN_THREADS]
+    constexpr int PX = 0, PY = WARP_CLIP_MAXV, QX = 2 * WARP_CLIP_MAXV, QY = 3 * WARP_CLIP_MAXV, E = 4 * WARP_CLIP_MAXV;
+    int n = 4;
+    SLOT(PX + 0) = -1.0; SLOT(PY + 0) = -1.0;
+    SLOT(PX + 1) = (double)W; SLOT(PY + 1) = -1.0;
+    SLOT(PX + 2) = (double)W; SLOT(PY + 2) = (double)H;
+    SLOT(PX + 3) = -1.0; SLOT(PY + 3) = (double)H;
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) {
+        int m = 0;
+        const double e0 = SLOT(E + 3 * k), e1 = SLOT(E + 3 * k + 1), e2 = SLOT(E + 3 * k + 2);
+#pragma unroll 1
+        for (int v = 0; v < n; ++v) {
+            const int u = v + 1 == n ? 0 : v + 1;
+            const double ax = SLOT(PX + v), ay = SLOT(PY + v), bx = SLOT(PX + u), by = SLOT(PY + u);
+            const double da = e0 * ax + e1 * ay + e2, db = e0 * bx + e1 * by + e2;
+            const bool ia = da >= 0.0, ib = db >= 0.0;
+            if (ia && m < WARP_CLIP_MAXV) { SLOT(QX + m) = ax; SLOT(QY + m) = ay; ++m; }
+            if (ia != ib && m < WARP_CLIP_MAXV) {
+                const double t = da / (da - db);
+                SLOT(QX + m) = ax + t * (bx - ax);
+                SLOT(QY + m) = ay + t * (by - ay);
+                ++m;
+            }
+        }
+        n = m;
+        if (n == 0) return false;
+#pragma unroll 1
+        for (int v = 0; v < n; ++v) { SLOT(PX + v) = SLOT(QX + v); SLOT(PY + v) = SLOT(QY + v); }
+    }
+    double xa = SLOT(PX), xb = xa, ya = SLOT(PY), yb = ya;
+#pragma unroll 1
+    for (int v = 1; v < n; ++v) {
+        xa = fmin(xa, SLOT(PX + v)); xb = fmax(xb, SLOT(PX + v));
+        ya = fmin(ya, SLOT(PY + v)); yb = fmax(yb, SLOT(PY + v));
+    }
+    j0 = max(0, (int)floor(xa) - 1); j1 = min(W - 1, (int)ceil(xb) + 1);
+    i0 = max(0, (int)floor(ya) - 1); i1 = min(H - 1, (int)ceil(yb) + 1);
+    return j0 <= j1 && i0 <= i1;
+}
+
+__device__ __forceinline__ WarpScan warp_scan_none()
+{
+    WarpScan z;
+    z.u0 = 0; z.u1 = -1; z.len = 0; z.swap = 0; z.a = 0.0; z.s = 0.0; z.uc = 0.0;
+    return z;
+}
+
+__device__ __forceinline__ WarpScan warp_scan_box(int i0, int i1, int j0, int j1)
+{
+    WarpScan z;
+    z.u0 = i0; z.u1 = i1; z.len = j1 - j0 + 1; z.swap = 0; z.a = (double)j0; z.s = 0.0; z.uc = 0.0;
+    return z;
+}
+
+// warp_bwd_scans: one lane per 2 x 2 block of source texels -> its (up to two) candidate scans of the destination pixels
+// whose source position can lie in [2bx-1, 2bx+2) x [2by-1, 2by+2).  force_clip: take the clipping path for every block
+// (a test knob: MVDETR_WARP_BWD_GEOMETRY=clip).  Blocks with more than heavy_above candidates are listed apart.
+template <typename T>
+__global__ __launch_bounds__(WARP_SCAN_THREADS) void warp_bwd_scans(const T *__restrict__ Mv, int N, int h, int w, int H,
+                                                                    int W, int force_clip, int heavy_above,
+                                                                    WarpScan *__restrict__ scans, int *__restrict__ lists,
+                                                                    int *__restrict__ counts)
+{
+    __shared__ double clip[WARP_CLIP_SLOTS * WARP_SCAN_THREADS];
+    const int bw2 = (w + 1) / 2, bh2 = (h + 1) / 2;
+    const int64_t idx = (int64_t)blockIdx.x * WARP_SCAN_THREADS + threadIdx.x;
+    if (idx >= (int64_t)N * bh2 * bw2) return;
+    const int n = (int)(idx / ((int64_t)bh2 * bw2)), rem = (int)(idx - (int64_t)n * bh2 * bw2);
+    const int by = rem / bw2, bx = rem - by * bw2;
+    const double xl = 2.0 * bx - 1.0, xh = 2.0 * bx + 2.0, yl = 2.0 * by - 1.0, yh = 2.0 * by + 2.0;
+    const T *Mn = Mv + (int64_t)n * 9;
+    double *const lds = clip + threadIdx.x;
+    WarpScan b0, b1;
+    [&] {
+    const double m0 = Mn[0], m1 = Mn[1], m2 = Mn[2], m3 = Mn[3], m4 = Mn[4], m5 = Mn[5], m6 = Mn[6],
+                 m7 = Mn[7], m8 = Mn[8];
+    b0 = warp_scan_none();
+    b1 = warp_scan_none();
+    // kornia's chain: position = p * size / (size - 1) - 0.5 for the source pixel p = M^-1 (j, i, 1)
+    const double wd = w == 1 ? 1e-14 : (double)(w - 1), hd = h == 1 ? 1e-14 : (double)(h - 1);
+    const double ax = (double)w / wd, ay = (double)h / hd;
+    const double det = m0 * (m4 * m8 - m5 * m7) + m1 * (m5 * m6 - m3 * m8) + m2 * (m3 * m7 - m4 * m6);
+    const double rdet = 1.0 / det;
+    // singular or non-finite matrix: the forward's positions are all inf / NaN -> zeros everywhere, no gradient
+    if (!(fabs(rdet) <= 1.79e308) || !(fabs(det) <= 1.79e308)) return;
+    bool fast = !force_clip;
+    double X[4], Y[4];
+    int pos = 0, neg = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        xmin = min(xmin, __shfl_xor(xmin, o, 64));
-        xmax = max(xmax, __shfl_xor(xmax, o, 64));
-        ymin = min(ymin, __shfl_xor(ymin, o, 64));
-        ymax = max(ymax, __shfl_xor(ymax, o, 64));
+    for (int k = 0; k < 4; ++k) {
+        const double sx = (k & 1) ? xh : xl, sy = (k & 2) ? yh : yl;
+        const double qx = (sx + 0.5) / ax, qy = (sy + 0.5) / ay;                    // source pixel
+        const double dx = m0 * qx + m1 * qy + m2, dy = m3 * qx + m4 * qy + m5, dz = m6 * qx + m7 * qy + m8;
+        pos += dz > 0.0;
+        neg += dz < 0.0;
+        X[k] = dx / dz;
+        Y[k] = dy / dz;
+        if (!(fabs(X[k]) <= 1e300) || !(fabs(Y[k]) <= 1e300)) fast = false;
     }
-    if (lane == 0) { box[wave][0] = xmin; box[wave][1] = xmax; box[wave][2] = ymin; box[wave][3] = ymax; }
-    __syncthreads();
-    xmin = min(min(box[0][0], box[1][0]), min(box[2][0], box[3][0]));
-    xmax = max(max(box[0][1], box[1][1]), max(box[2][1], box[3][1]));
-    ymin = min(min(box[0][2], box[1][2]), min(box[2][2], box[3][2]));
-    ymax = max(max(box[0][3], box[1][3]), max(box[2][3], box[3][3]));
-    const int64_t plane = (int64_t)h * w, oplane = (int64_t)H * W;
-    float *const op = dst + (int64_t)n * C * oplane + (int64_t)i * W + j;
-    if (xmax < xmin) {                                        // the whole tile misses the image
-        if (live)
-            for (int c = 0; c < C; ++c) op[c * oplane] = 0.f;
-        return;
+    if (fast && (pos == 4 || neg == 4)) {
+        // the square is on one side of the horizon: its image is the convex hull of the four corner images.  Five
+        // ways to scan it: rows or columns sheared along the image of the square's x or y side, or plain rows.
+        constexpr double MARGIN = 0.01;                      // pixels; fp64 rounding of the hull is ~1e-12
+        double best = 1e300;
+#pragma unroll 1
+        for (int opt = 0; opt < 5; ++opt) {
+            const int swap = opt >> 1 & (opt < 4);           // options 2, 3: lines are columns
+            const int edge = opt & 1;                        // sheared along corner 0 -> 1 (x side) or 0 -> 2 (y side)
+            const double Xe = edge ? X[2] : X[1], Ye = edge ? Y[2] : Y[1];
+            const double du = swap ? Xe - X[0] : Ye - Y[0], dv = swap ? Ye - Y[0] : Xe - X[0];
+            double sh = 0.0;
+            if (opt < 4) {
+                if (!(fabs(du) > 1e-3 * fabs(dv)) || !(fabs(du) > 1e-9)) continue;   // (nearly) along the lines: no shear
+                sh = dv / du;
+            }
+            const double uc = swap ? X[0] : Y[0];
+            double ua = 0, ub = 0, va = 0, vb = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double u = swap ? X[k] : Y[k], v = (swap ? Y[k] : X[k]) - sh * (u - uc);
+                ua = k ? fmin(ua, u) : u; ub = k ? fmax(ub, u) : u;
+                va = k ? fmin(va, v) : v; vb = k ? fmax(vb, v) : v;
+            }
+            const double U = swap ? (double)W : (double)H;
+            const double u0 = fmax(ceil(ua - MARGIN), 0.0), u1 = fmin(floor(ub + MARGIN), U - 1.0);
+            WarpScan z = warp_scan_none();
+            double cost = 0.0;
+            if (u0 <= u1) {
+                const double len = floor(vb - va + 2.0 * MARGIN) + 2.0;
+                cost = (u1 - u0 + 1.0) * len;
+                if (!(cost < 2.0e9)) continue;
+                z.u0 = (int)u0; z.u1 = (int)u1; z.len = (int)len; z.swap = swap; z.a = va - MARGIN; z.s = sh; z.uc = uc;
+            }
+            if (cost < best) { best = cost; b0 = z; }
+        }
+        if (best < 1e300) return;
     }
-    const int PW = xmax - xmin + 1, PH = ymax - ymin + 1;
-    const int64_t P = (int64_t)PW * PH;
-    const float *const sview = src + (int64_t)n * C * plane;
-    if (P > WARP_PATCH_FLOATS) {
-        // magnification too large for a patch: per-lane gathers (the formulation of warp_fwd)
-        if (live) {
-            const int64_t o00 = (int64_t)sc.y0 * w + sc.x0;
-            for (int c = 0; c < C; ++c) {
-                float val = 0.f;
-                if (use) {
-                    const float *sp = sview + c * plane + o00;
-                    float a, b, cc, d;
-                    load_pair(sp, sc.v00, sc.v01, a, b);
-                    load_pair(sp + w, sc.v10, sc.v11, cc, d);
-                    val = w00 * a + w01 * b + w10 * cc + w11 * d;
+    {
+        // rows of adj(M) acting on (j, i, 1) (a positive or negative multiple of M^-1: both signs are clipped)
+        const double A0[3] = {m4 * m8 - m5 * m7, m2 * m7 - m1 * m8, m1 * m5 - m2 * m4};
+        const double A1[3] = {m5 * m6 - m3 * m8, m0 * m8 - m2 * m6, m2 * m3 - m0 * m5};
+        const double A2[3] = {m3 * m7 - m4 * m6, m1 * m6 - m0 * m7, m0 * m4 - m1 * m3};
+        double big = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) big = fmax(big, fmax(fabs(A0[c]), fmax(fabs(A1[c]), fabs(A2[c]))));
+        int4 c0 = make_int4(0, -1, 0, -1), c1 = c0;
+        if (!(big > 0.0 && big <= 1e300)) {
+            c0 = make_int4(0, H - 1, 0, W - 1);                                      // cannot reason: scan everything
+        } else {
+            const double sc = 1.0 / big;
+#pragma unroll 1
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                const double sg = sgn ? -sc : sc;
+                constexpr int E = 4 * WARP_CLIP_MAXV;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double gx = ax * A0[c] - 0.5 * A2[c], gy = ay * A1[c] - 0.5 * A2[c], gz = A2[c];
+                    lds[(E + 0 + c) * WARP_SCAN_THREADS] = sg * gz;
+                    lds[(E + 3 + c) * WARP_SCAN_THREADS] = sg * (gx - xl * gz);
+                    lds[(E + 6 + c) * WARP_SCAN_THREADS] = sg * (xh * gz - gx);
+                    lds[(E + 9 + c) * WARP_SCAN_THREADS] = sg * (gy - yl * gz);
+                    lds[(E + 12 + c) * WARP_SCAN_THREADS] = sg * (yh * gz - gy);
                 }
-                op[c * oplane] = val;
+                // (most squares that cross the horizon map outside the destination: one inequality fails at all four
+                // corners of the rectangle -> nothing to clip)
+                bool empty = false;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const double e0 = lds[(E + 3 * k) * WARP_SCAN_THREADS], e1 = lds[(E + 3 * k + 1) * WARP_SCAN_THREADS],
+                                 e2 = lds[(E + 3 * k + 2) * WARP_SCAN_THREADS];
+                    const double r00 = e2 - e0 - e1, r10 = e0 * W - e1 + e2, r11 = e0 * W + e1 * H + e2, r01 = e1 * H - e0 + e2;
+                    empty = empty || (r00 < 0.0 && r10 < 0.0 && r11 < 0.0 && r01 < 0.0);
+                }
+                int i0, i1, j0, j1;
+                if (!empty && warp_clip_box(lds, H, W, i0, i1, j0, j1)) {
+                    const int4 b = make_int4(i0, i1, j0, j1);
+                    if (sgn) c1 = b; else c0 = b;
+                }
+            }
+            // two overlapping boxes would count their common pixels twice: merge them
+            if (c0.x <= c0.y && c1.x <= c1.y && c0.x <= c1.y && c1.x <= c0.y && c0.z <= c1.w && c1.z <= c0.w) {
+                c0 = make_int4(min(c0.x, c1.x), max(c0.y, c1.y), min(c0.z, c1.z), max(c0.w, c1.w));
+                c1 = make_int4(0, -1, 0, -1);
             }
         }
-        return;
+        if (c0.x <= c0.y) b0 = warp_scan_box(c0.x, c0.y, c0.z, c0.w);
+        if (c1.x <= c1.y) b1 = warp_scan_box(c1.x, c1.y, c1.z, c1.w);
     }
-    const int Pi = (int)P;
-    const int CC = min(WARP_P_CC, WARP_PATCH_FLOATS / Pi);
-    const int o00 = use ? (sc.y0 - ymin) * PW + (sc.x0 - xmin) : 0;
-    for (int c0 = 0; c0 < C; c0 += CC) {
-        const int nc = min(CC, C - c0);
-        // patch rows of nc channels: wave `wave` takes rows wave, wave + 4, ... of the nc * PH rows; lanes = columns
-        for (int rr = wave; rr < nc * PH; rr += 4) {
-            const int ch = rr / PH, py = rr - ch * PH, sy = ymin + py;
-            const float *srow = sview + (int64_t)(c0 + ch) * plane + (int64_t)sy * w;
-            float *prow = patch + ch * Pi + py * PW;
-            const bool yok = (unsigned)sy < (unsigned)h;
-            for (int px = lane; px < PW; px += 64) {
-                const int sx = xmin + px;
-                prow[px] = yok && (unsigned)sx < (unsigned)w ? srow[sx] : 0.f;
+    }();
+    scans[2 * idx] = b0;
+    scans[2 * idx + 1] = b1;
+    // light blocks (incl. those without candidates: they still store zeros) and heavy ones go to separate work lists
+    const int64_t c0 = b0.u1 >= b0.u0 ? (int64_t)(b0.u1 - b0.u0 + 1) * b0.len : 0;
+    const int64_t c1 = b1.u1 >= b1.u0 ? (int64_t)(b1.u1 - b1.u0 + 1) * b1.len : 0;
+    const int cls = c0 + c1 > heavy_above;
+    // one atomic per wave and list (25 K atomics on one address take 11 ns each: 285 us)
+    const int lane = threadIdx.x & 63;
+    const uint64_t same = cls ? __ballot(cls == 1) : __ballot(cls == 0);
+    const int leader = __ffsll((unsigned long long)same) - 1;
+    int slot = 0;
+    if (lane == leader) slot = atomicAdd(counts + cls, __popcll(same));
+    slot = __shfl(slot, leader, 64) + __popcll(same & ((1ull << lane) - 1ull));
+    lists[(cls ? (int64_t)N * bh2 * bw2 : 0) + slot] = (int)idx;
+}
+#undef SLOT
+
+constexpr int WARP_GU = 8;          // grad_dst loads in flight per lane
+constexpr int WARP_HEAVY = 128;     // blocks with more candidates than this get a whole workgroup
+constexpr int WARP_HEAVY_WGS = 2048;
+
+// The candidate rounds first, first + stride, ... (64 candidates each) of one 2 x 2 texel block, run by one wave.
+// Lane = (hit stream, channel chunk): with G = 2^lgG >= C/4 lanes per stream the wave runs 64 / G streams that take the
+// compacted hits round-robin (two at 128 channels).
+template <typename T>
+__device__ __forceinline__ void warp_gather_rounds(
+    const T *__restrict__ gchunk, const T (&Mn)[9], const WarpScan *__restrict__ scans, int64_t blk, int n, int bx, int by,
+    int C, int h, int w, int H, int W, int nearest, int lgG, bool has_ch, int first, int stride, WarpRec<T> *mine,
+    T (&acc)[4][16 / (int)sizeof(T)])
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    using Rec = WarpRec<T>;
+    const int S = 64 >> lgG;
+    const int lane = threadIdx.x & 63, st = lane >> lgG;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int bsel = 0; bsel < 2; ++bsel) {
+        const WarpScan sc = scans[2 * blk + bsel];
+        const int cnt = sc.u1 >= sc.u0 && sc.len > 0 ? (sc.u1 - sc.u0 + 1) * sc.len : 0;
+        const int V = sc.swap ? H : W;
+        const float rlen = 1.0f / (float)sc.len;
+        const bool small = cnt < (1 << 22);                   // k * rlen is then within one of the quotient
+        for (int base = first * 64; base < cnt; base += stride * 64) {
+            const int k = base + lane;
+            bool hit = false;
+            Rec r;
+            r.pix = 0;
+            r.mask = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r.w[t] = T(0);
+            if (k < cnt) {
+                int du;
+                if (small) {
+                    du = (int)((float)k * rlen);
+                    du -= du * sc.len > k;
+                    du += (du + 1) * sc.len <= k;
+                } else {
+                    du = k / sc.len;
+                }
+                const int u = sc.u0 + du;
+                const int v = (int)ceil(sc.a + sc.s * ((double)u - sc.uc)) + (k - du * sc.len);
+                const int i = sc.swap ? v : u, j = sc.swap ? u : v;
+                if (v >= 0 && v < V && fabs(source_pz(Mn, i, j)) > 1e-8) {
+                    double x, y;
+                    source_position(Mn, i, j, h, w, x, y);
+                    const SrcCoord c = make_coord(x, y, h, w, nearest);
+                    const int dx = c.x0 - 2 * bx, dy = c.y0 - 2 * by;              // corner 00 relative to the block
+                    if (c.any && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) {
+                        const T w00 = T(c.wy0 * c.wx0), w01 = T(c.wy0 * c.wx1);
+                        const T w10 = T(c.wy1 * c.wx0), w11 = T(c.wy1 * c.wx1);
+                        // corner (cy, cx) lies on block texel (dy + cy, dx + cx) when that is in {0, 1}^2
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int ty = t >> 1, tx = t & 1, cy = ty - dy, cx = tx - dx;
+                            if (cy >= 0 && cy <= 1 && cx >= 0 && cx <= 1) {
+                                const bool ok = cy ? (cx ? c.v11 : c.v10) : (cx ? c.v01 : c.v00);
+                                const T ww = cy ? (cx ? w11 : w10) : (cx ? w01 : w00);
+                                if (ok) {
+                                    r.mask |= 1 << t;
+                                    r.w[t] = ww;
+                                }
+                            }
+                        }
+                        r.pix = ((n * H + i) * W + j) * C;                          // element offset (< 2^31: checked on the host)
+                        hit = r.mask != 0;
+                    }
+                }
             }
-        }
-        __syncthreads();
-        if (live) {
-            const float *pp = patch + o00;
-#pragma unroll 4
-            for (int ch = 0; ch < nc; ++ch) {
-                const float *q = pp + ch * Pi;
-                op[(int64_t)(c0 + ch) * oplane] = w00 * q[0] + w01 * q[1] + w10 * q[PW] + w11 * q[PW + 1];
+            const uint64_t hits = __ballot(hit);
+            const int nhit = __popcll(hits);
+            if (hit) mine[__popcll(hits & below)] = r;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // stream st takes hits st, st + S, ...: WARP_GU of them in flight
+            for (int q = st; q < nhit; q += WARP_GU * S) {
+                Pack<T, VEC> g[WARP_GU];
+#pragma unroll
+                for (int u = 0; u < WARP_GU; ++u) {           // the loads first (only the offsets are read here) ...
+                    const int off = mine[min(q + u * S, nhit - 1)].pix;
+                    g[u] = has_ch ? Pack<T, VEC>::load(gchunk + off) : Pack<T, VEC>::zero();
+                }
+#pragma unroll
+                for (int u = 0; u < WARP_GU; ++u) {           // ... then weights and masks, re-read from LDS
+                    const int qq = q + u * S;
+                    const Rec rr = mine[min(qq, nhit - 1)];
+                    const int mask = qq < nhit ? rr.mask : 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const bool on = (mask >> t) & 1;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[t][v] = on ? acc[t][v] + rr.w[t] * g[u].v[v] : acc[t][v];
+                    }
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
     }
+    // the streams' partial sums, in a fixed order
+    for (int off = 1 << lgG; off < 64; off <<= 1)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[t][v] += __shfl_xor(acc[t][v], off, 64);
+}
+
+// Workgroups [0, WARP_HEAVY_WGS): the heavy blocks (far field: hundreds of candidates), one workgroup per (block, channel
+// group) at a time, its four waves taking the candidate rounds in turn and adding their partial sums in wave order.
+// The other workgroups: one WAVE per (light block, channel group).  lists = [light blocks | heavy blocks], counts = their
+// lengths (filled by warp_bwd_scans; the order inside a list does not matter).
+template <typename T>
+__global__ __launch_bounds__(256) void warp_bwd_gather(
+    const T *__restrict__ grad_dst, const T *__restrict__ Mv, const WarpScan *__restrict__ scans,
+    const int *__restrict__ lists, const int *__restrict__ counts, int N, int C, int h, int w, int H, int W, int nearest,
+    int lgG, int cgroups, T *__restrict__ grad_src)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    __shared__ WarpRec<T> recs[4][64];
+    __shared__ T part[3][64][4 * VEC];                        // heavy path: the partial sums of waves 1..3
+    const int G = 1 << lgG;
+    const int tid = threadIdx.x, lane = tid & 63, lg = lane & (G - 1), st = lane >> lgG;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: block, view, matrix and scans live in SGPRs)
+    const int bw2 = (w + 1) / 2, bh2 = (h + 1) / 2;
+    const int64_t nblk = (int64_t)N * bh2 * bw2;
+    const bool heavy = blockIdx.x < WARP_HEAVY_WGS;
+    const int64_t nitems = (int64_t)(heavy ? counts[1] : counts[0]) * cgroups;
+    const int *const list = heavy ? lists + nblk : lists;
+    for (int64_t item = heavy ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x - WARP_HEAVY_WGS) * 4 + wv; item < nitems;
+         item += heavy ? (int64_t)WARP_HEAVY_WGS : nitems) {
+        const int64_t blk = list[item / cgroups];
+        const int cgi = (int)(item % cgroups);
+        const int n = (int)(blk / ((int64_t)bh2 * bw2));
+        const int rem = (int)(blk - (int64_t)n * bh2 * bw2);
+        const int by = rem / bw2, bx = rem - by * bw2;
+        const int chunk = cgi * G + lg;
+        const bool has_ch = chunk < C / VEC;
+        T Mn[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Mn[k] = Mv[(int64_t)n * 9 + k];
+        T acc[4][VEC];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[t][v] = T(0);
+        warp_gather_rounds<T>(grad_dst + (int64_t)chunk * VEC, Mn, scans, blk, n, bx, by, C, h, w, H, W, nearest, lgG, has_ch,
+                              heavy ? wv : 0, heavy ? 4 : 1, recs[wv], acc);
+        if (heavy) {
+            if (wv > 0 && st == 0)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) part[wv - 1][lg][t * VEC + v] = acc[t][v];
+            __syncthreads();
+            if (wv == 0 && st == 0)
+                for (int o = 0; o < 3; ++o)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[t][v] += part[o][lg][t * VEC + v];
+            __syncthreads();
+        }
+        if (has_ch && st == 0 && (!heavy || wv == 0)) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int Y = 2 * by + (t >> 1), X = 2 * bx + (t & 1);
+                if (Y < h && X < w) {
+                    Pack<T, VEC> o;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o.v[v] = acc[t][v];
+                    o.store(grad_src + (((int64_t)n * h + Y) * w + X) * C + (int64_t)chunk * VEC);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void warp_bwd_stragglers(
+    const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W, int nearest,
+    T *__restrict__ grad_src)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (int64_t)N * H * W) return;
+    const int n = (int)(p / ((int64_t)H * W)), rem = (int)(p - (int64_t)n * H * W), i = rem / W, j = rem - i * W;
+    const T *Mn = Mv + (int64_t)n * 9;
+    if (fabs(source_pz(Mn, i, j)) > 1e-8) return;                  // NaN: the forward stores zeros there, no gradient
+    double x, y;
+    source_position(Mn, i, j, h, w, x, y);
+    const SrcCoord sc = make_coord(x, y, h, w, nearest);
+    if (!sc.any) return;
+    const T w00 = T(sc.wy0 * sc.wx0), w01 = T(sc.wy0 * sc.wx1), w10 = T(sc.wy1 * sc.wx0), w11 = T(sc.wy1 * sc.wx1);
+    T *gp = grad_src + (((int64_t)n * h + sc.y0) * w + sc.x0) * C;
+    const T *g = grad_dst + p * C;
+    const int64_t rowC = (int64_t)w * C;
+    for (int c = 0; c < C; ++c) {
+        if (sc.v00) atomicAdd(gp + c, w00 * g[c]);
+        if (sc.v01) atomicAdd(gp + C + c, w01 * g[c]);
+        if (sc.v10) atomicAdd(gp + rowC + c, w10 * g[c]);
+        if (sc.v11) atomicAdd(gp + rowC + C + c, w11 * g[c]);
+    }
+}
+
+// Which kernel the last warp call of this process launched (tests assert the layout routes; bench.py reports it).  Not
+// thread-local: autograd runs the backward on its own thread.
+static std::atomic<const char *> g_warp_last_kernel{"none"};
+
+static int warp_bwd_impl()
+{
+    // MVDETR_WARP_BWD_IMPL = gather (default) | scatter: the atomic kernels, kept for comparison and as the fallback for
+    // shapes the gather does not take
+    const char *e = getenv("MVDETR_WARP_BWD_IMPL");
+    return e && !strcmp(e, "scatter") ? 1 : 0;
+}
+
+template <typename T>
+static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv, int N, int C, int h, int w, int H,
+                                  int W, int nearest, T *grad_src)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const int chunks = C / VEC;
+    int lgG = 0;
+    while ((1 << lgG) < chunks && lgG < 6) ++lgG;
+    const int G = 1 << lgG, cgroups = (chunks + G - 1) / G;
+    const int64_t nblk = (int64_t)N * ((h + 1) / 2) * ((w + 1) / 2);
+    const int64_t wgs = (nblk * cgroups + 3) / 4;
+    const int64_t npix = (int64_t)N * H * W;
+    if (wgs > 0x7fffffffLL || npix * C > 0x7fffffffLL) return (int)hipErrorNotSupported;
+    const char *ge = getenv("MVDETR_WARP_BWD_GEOMETRY");
+    const int force_clip = ge && !strcmp(ge, "clip");
+    // stream-ordered scratch: [scans: 2 per block | work lists: light, heavy | their two lengths]
+    const size_t scan_bytes = (size_t)nblk * 2 * sizeof(WarpScan), list_bytes = (size_t)nblk * 2 * sizeof(int);
+    char *scratch = nullptr;
+    hipError_t rc = hipMallocAsync(reinterpret_cast<void **>(&scratch), scan_bytes + list_bytes + 2 * sizeof(int), st);
+    if (rc != hipSuccess) return (int)rc;
+    WarpScan *scans = reinterpret_cast<WarpScan *>(scratch);
+    int *lists = reinterpret_cast<int *>(scratch + scan_bytes), *counts = lists + 2 * nblk;
+    rc = hipMemsetAsync(counts, 0, 2 * sizeof(int), st);
+    const char *he = getenv("MVDETR_WARP_BWD_HEAVY");        // (test knob: 0 = every block with candidates is "heavy")
+    const int heavy_above = he ? atoi(he) : WARP_HEAVY;
+    hipLaunchKernelGGL((warp_bwd_scans<T>), dim3((unsigned)((nblk + WARP_SCAN_THREADS - 1) / WARP_SCAN_THREADS)),
+                       dim3(WARP_SCAN_THREADS), 0, st, Mv, N, h, w, H, W, force_clip, heavy_above, scans, lists, counts);
+    hipLaunchKernelGGL((warp_bwd_gather<T>), dim3((unsigned)(wgs + WARP_HEAVY_WGS)), dim3(256), 0, st, grad_dst, Mv, scans,
+                       lists, counts, N, C, h, w, H, W, nearest, lgG, cgroups, grad_src);
+    hipLaunchKernelGGL((warp_bwd_stragglers<T>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, grad_dst, Mv, N, C,
+                       h, w, H, W, nearest, grad_src);
+    if (rc == hipSuccess) rc = hipGetLastError();
+    (void)hipFreeAsync(scratch, st);
+    return (int)rc;
 }
 
 template <typename T>
@@ -512,13 +924,21 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
                       int H, int W, int nhwc, T *o)
 {
     if (N < 0 || C < 0 || h <= 0 || w <= 0 || H < 0 || W < 0) return (int)hipErrorInvalidValue;
+    if (nhwc & ~7) return (int)hipErrorInvalidValue;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t npix = (int64_t)N * H * W;
+    if (backward) {
+        // grad_src is OVERWRITTEN: the gather stores every element, the scatter kernels start from zeros
+        const int64_t nsrc = (int64_t)N * C * h * w;
+        if (nsrc == 0) return 0;
+        if (!o) return (int)hipErrorInvalidValue;
+        if (npix == 0) return (int)hipMemsetAsync(o, 0, (size_t)nsrc * sizeof(T), st);
+    }
     if (npix == 0 || C == 0) return 0;
     if (!a || !Mv || !o) return (int)hipErrorInvalidValue;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (nhwc & ~7) return (int)hipErrorInvalidValue;
     const int nearest = (nhwc >> 2) & 1;                   // bit 2: mode='nearest'
     nhwc &= 3;
+    const size_t src_bytes = (size_t)N * C * h * w * sizeof(T);
     if (nhwc & 2) {
         // channel-last source: implemented for channel-last destinations, whole 16-byte chunks per pixel and a
         // view that fits 32-bit element offsets
@@ -532,6 +952,7 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
                     const int64_t nb2 = (int64_t)N * ((H + WARP_NC_TH - 1) / WARP_NC_TH) * ((W + WARP_NC_TW - 1) / WARP_NC_TW);
                     if (nb2 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
                     hipLaunchKernelGGL(warp_fwd_cl_nchw, dim3((unsigned)nb2), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+                    g_warp_last_kernel = "warp_fwd_cl_nchw";
                     return (int)hipGetLastError();
                 }
             }
@@ -539,31 +960,40 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
         }
         const int64_t nb = warp_grid(N, H, W, 1);
         if (nb > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-        if (!backward)
+        if (!backward) {
             hipLaunchKernelGGL((warp_fwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
-        else
-            hipLaunchKernelGGL((warp_bwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
-        return (int)hipGetLastError();
-    }
-    if constexpr (sizeof(T) == 4) {
-        if (!backward && !nhwc && C > 1) {
-            // NCHW -> NCHW, fp32: LDS source patches
-            const int64_t nb3 = (int64_t)N * ((H + WARP_P_TH - 1) / WARP_P_TH) * ((W + WARP_P_TW - 1) / WARP_P_TW);
-            if (nb3 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-            hipLaunchKernelGGL(warp_fwd_nchw_patch, dim3((unsigned)nb3), dim3(256), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+            g_warp_last_kernel = "warp_fwd_cl";
             return (int)hipGetLastError();
         }
+        if (!warp_bwd_impl()) {
+            const int rc = warp_bwd_gather_launch<T>(st, a, Mv, N, C, h, w, H, W, nearest, o);
+            if (rc != (int)hipErrorNotSupported) {
+                g_warp_last_kernel = "warp_bwd_gather";
+                return rc;
+            }
+        }
+        hipError_t rc = hipMemsetAsync(o, 0, src_bytes, st);
+        if (rc != hipSuccess) return (int)rc;
+        hipLaunchKernelGGL((warp_bwd_cl<T>), dim3((unsigned)nb), dim3(WARP_CL_THREADS), 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+        g_warp_last_kernel = "warp_bwd_cl";
+        return (int)hipGetLastError();
     }
     const int groups = (C + WARP_CH - 1) / WARP_CH;
     const int64_t blocks = warp_grid(N, H, W, groups);
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(WARP_PIX * WARP_SUB);
     if (!backward) {
+        // NCHW source: 8x8-tile gather kernel for both destination layouts (91 us / 28 % at Wildtrack size for
+        // NCHW -> NCHW, the literal layouts of the kornia call; every replacement tried was slower)
         if (nhwc) hipLaunchKernelGGL((warp_fwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
         else hipLaunchKernelGGL((warp_fwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+        g_warp_last_kernel = nhwc ? "warp_fwd<NHWC>" : "warp_fwd<NCHW>";
     } else {
+        hipError_t rc = hipMemsetAsync(o, 0, src_bytes, st);
+        if (rc != hipSuccess) return (int)rc;
         if (nhwc) hipLaunchKernelGGL((warp_bwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
         else hipLaunchKernelGGL((warp_bwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
+        g_warp_last_kernel = nhwc ? "warp_bwd<NHWC>" : "warp_bwd<NCHW>";
     }
     return (int)hipGetLastError();
 }
@@ -604,6 +1034,8 @@ template <typename T> static int transpose_entry(void *stream, const T *src, int
 }  // namespace mvdetr
 
 extern "C" {
+
+const char *mvdetr_warp_last_kernel(void) { return mvdetr::g_warp_last_kernel.load(); }
 
 int mvdetr_transpose_f32(void *stream, const float *src, int n, int rows, int cols, float *dst)
 {

@@ -31,13 +31,21 @@ def _launch(name, a, M, n, c, h, w, H, W, layout, out):
 
 
 def _transpose(x, n, rows, cols):
-    """[n, rows, cols] -> [n, cols, rows] (contiguous CUDA tensor) with the library's tiled transpose."""
+    """[n, rows, cols] -> [n, cols, rows] (contiguous CUDA tensor) with the library's tiled transpose (grid limits:
+    n <= 65535 and rows <= 64 * 65535; beyond them a strided torch copy does the same job)."""
+    if n > 65535 or (rows + 63) // 64 > 65535:
+        return x.view(n, rows, cols).transpose(1, 2).contiguous()
     out = torch.empty((n, cols, rows), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
         rc = getattr(_lib.lib(), f"mvdetr_transpose_{_lib.suffix(x.dtype)}")(
             _lib.current_stream_ptr(x.device), x.data_ptr(), n, rows, cols, out.data_ptr())
     _lib.check(rc, "transpose")
     return out
+
+
+def last_kernel() -> str:
+    """Name of the device kernel the last warp call on this thread launched (tests / bench introspection)."""
+    return _lib.lib().mvdetr_warp_last_kernel().decode()
 
 
 def _channel_last_source(src, channels_last_out):
@@ -81,18 +89,20 @@ class WarpPerspectiveFunction(Function):
         (M,) = ctx.saved_tensors
         n, c, h, w, H, W, layout = ctx.geom
         near = layout & NEAREST
-        if grad_out.is_cuda and (c * grad_out.element_size()) % 16 == 0:
-            # channel-last on both sides whatever the forward's layouts were: the scatter is bound by atomic
-            # REQUESTS, and with channels innermost a corner is one contiguous run (4.7 ms -> 0.39 ms at Wildtrack
-            # size); NCHW gradients are transposed on the way in / out (a copy each, ~0.1 ms together)
+        if grad_out.is_cuda and (c * grad_out.element_size()) % 16 == 0 and h * w * c < 2 ** 31:
+            # channel-last on both sides whatever the forward's layouts were: there the gradient is a GATHER over the
+            # destination pixels whose footprint touches each source texel (csrc/warp_perspective.hip: no atomics,
+            # deterministic, grad_src written once); NCHW gradients are transposed on the way in / out
             g = grad_out.contiguous() if layout & DST_NHWC else _transpose(grad_out.contiguous(), n, c, H * W)
             grad_src = torch.empty((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device,
-                                   memory_format=torch.channels_last).zero_()
+                                   memory_format=torch.channels_last)
             _launch("backward", g, M, n, c, h, w, H, W, DST_NHWC | SRC_NHWC | near, grad_src)
             if ctx.src_was_cl:
                 return grad_src, None, None, None, None
             return _transpose(grad_src.permute(0, 2, 3, 1), n, h * w, c).view(n, c, h, w), None, None, None, None
-        grad_src = torch.zeros((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device)
+        # the device entry overwrites grad_src (it zeroes it itself before scattering); the host entry accumulates
+        alloc = torch.empty if grad_out.is_cuda else torch.zeros
+        grad_src = alloc((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device)
         _launch("backward", grad_out.contiguous(), M, n, c, h, w, H, W, (layout & DST_NHWC) | near, grad_src)
         return grad_src, None, None, None, None
 

@@ -239,3 +239,222 @@ def test_channels_last_source_gradcheck(warp):
     src = t(g["src"])[:, :4].contiguous().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     M = t(g["M"])
     assert torch.autograd.gradcheck(lambda s: warp(s, M, (6, 10), channels_last_out=True), (src,))
+
+
+# ---- which kernel runs per layout route; the gather backward --------------------------------------------------------
+def _last_kernel():
+    from mvdetr_amd.ops.warp import last_kernel
+    return last_kernel()
+
+
+def test_kernel_name_per_layout_route(warp):
+    """an experiment once became the default fp32 NCHW -> NCHW forward unnoticed (5.5x slower).  Every layout
+    route is pinned to its kernel here (mvdetr_warp_last_kernel)."""
+    M = wildtrack_mats(None)
+    src = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(0)).cuda()
+    src_cl = src.contiguous(memory_format=torch.channels_last)
+    warp(src, M, (120, 360))
+    assert _last_kernel() == "warp_fwd<NCHW>"                       # the literal kornia contract, mvdetr.py:194-195
+    warp(src.double(), M, (120, 360))
+    assert _last_kernel() == "warp_fwd<NCHW>"
+    warp(src, M, (120, 360), channels_last_out=True)
+    assert _last_kernel() == "warp_fwd_cl"                          # after the tiled transpose
+    warp(src_cl, M, (120, 360), channels_last_out=True)
+    assert _last_kernel() == "warp_fwd_cl"
+    warp(src_cl, M, (120, 360))
+    assert _last_kernel() == "warp_fwd_cl_nchw"
+    warp(src[:, :37], M, (120, 360), channels_last_out=True)        # 37 channels: no 16-byte chunks
+    assert _last_kernel() == "warp_fwd<NHWC>"
+    for s_in, nhwc in ((src, False), (src, True), (src_cl, True), (src_cl, False)):
+        leaf = s_in.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+        out = warp(leaf, M, (120, 360), channels_last_out=nhwc)
+        out.backward(torch.ones_like(out))
+        assert _last_kernel() == "warp_bwd_gather"
+    leaf = src[:, :37].detach().clone().requires_grad_(True)
+    warp(leaf, M, (120, 360)).sum().backward()
+    assert _last_kernel() == "warp_bwd<NCHW>"
+
+
+def _bwd_cl(go_nhwc, M, n, c, h, w, env=None, nearest=False):
+    """The channel-last backward entry through the C ABI; `env` = extra environment for this call."""
+    import os
+    from mvdetr_amd.ops import warp as warp_mod
+    H, W = go_nhwc.shape[1:3]
+    gs = torch.full((n, h, w, c), float("nan"), dtype=go_nhwc.dtype, device="cuda")     # must be overwritten
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        warp_mod._launch("backward", go_nhwc, M.to(device="cuda", dtype=go_nhwc.dtype).contiguous(), n, c, h, w, H, W, 3 | (4 if nearest else 0), gs)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k)
+            else:
+                os.environ[k] = v
+    return gs
+
+
+@pytest.mark.parametrize("aug", [None, 4])
+def test_backward_gather_wildtrack_size(warp, aug):
+    """Gather backward at full Wildtrack size: vs the fp32 C oracle (scatter order differs: 1e-4 relative to the largest
+    sum), vs the library's atomic scatter kernel, deterministic bit for bit, same result through the clipping geometry."""
+    M = wildtrack_mats(aug)
+    go = torch.randn(7, 120, 360, 128, generator=torch.Generator().manual_seed(2)).cuda()
+    g1 = _bwd_cl(go, M, 7, 128, 90, 160)
+    assert _last_kernel() == "warp_bwd_gather"
+    assert torch.isfinite(g1).all()
+    g2 = _bwd_cl(go, M, 7, 128, 90, 160)
+    assert torch.equal(g1, g2)                                       # deterministic
+    g3 = _bwd_cl(go, M, 7, 128, 90, 160, env={"MVDETR_WARP_BWD_GEOMETRY": "clip"})
+    assert (g1 - g3).abs().max().item() <= 1e-5 * (1 + g1.abs().max().item())    # other candidate scans: another fixed order
+    assert torch.equal(g1 == 0, g3 == 0)
+    for heavy_above in ("0", "1000000000"):                          # every block on the workgroup path / on the wave path
+        g4 = _bwd_cl(go, M, 7, 128, 90, 160, env={"MVDETR_WARP_BWD_HEAVY": heavy_above})
+        assert (g1 - g4).abs().max().item() <= 1e-5 * (1 + g1.abs().max().item()) and torch.equal(g1 == 0, g4 == 0)
+    gsc = _bwd_cl(go, M, 7, 128, 90, 160, env={"MVDETR_WARP_BWD_IMPL": "scatter"})
+    assert _last_kernel() == "warp_bwd_cl"
+    scale = 1 + gsc.abs().max().item()
+    assert (g1 - gsc).abs().max().item() <= 2e-5 * scale
+    assert torch.equal(g1 == 0, gsc == 0)                            # the same texels receive gradient
+    ref = c_oracle.warp_perspective_backward(go.permute(0, 3, 1, 2).cpu().double(), M.float().double(), (90, 160))
+    assert (g1.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item() <= 2e-5 * scale
+    # adjoint identity <go, warp(x)> == <bwd(go), x>
+    x = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(5)).cuda().contiguous(memory_format=torch.channels_last)
+    y = warp(x, M, (120, 360), channels_last_out=True)
+    lhs, rhs = (go.double() * y.double()).sum().item(), (g1.double() * x.permute(0, 2, 3, 1).double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0) + 1e-3
+
+
+def _horizon_mats(dtype=torch.float64):
+    """Homographies whose line at infinity crosses the SOURCE image (a horizon inside the view) and whose pre-image of the
+    line at infinity crosses the destination grid: the gather's clipping path, both signs of the homogeneous coordinate."""
+    Ms = []
+    for k, (a, b, c) in enumerate([(0.0, 0.11, -0.5), (0.03, -0.09, 0.4), (-0.05, 0.0, 0.6), (0.02, 0.13, -1.0)]):
+        A = torch.tensor([[2.1, 0.3 * k, 1.0], [-0.2, 2.4, 2.0 - k], [a, b, c]], dtype=torch.float64)
+        Ms.append(A)
+    return torch.stack(Ms).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("geometry_env", [None, "clip"])
+@pytest.mark.parametrize("nearest", [False, True])
+def test_backward_gather_horizon_inside_the_view(warp, dtype, geometry_env, nearest):
+    M = _horizon_mats()
+    n, c, h, w, H, W = 4, 8, 9, 16, 14, 33
+    env = {"MVDETR_WARP_BWD_GEOMETRY": geometry_env} if geometry_env else None
+    go = torch.randn(n, H, W, c, generator=torch.Generator().manual_seed(7), dtype=torch.float64)
+    gs = _bwd_cl(go.to(dtype).cuda(), M.to(dtype), n, c, h, w, env=env, nearest=nearest)
+    assert _last_kernel() == "warp_bwd_gather"
+    # reference: autograd through the oracle's own forward (torch ops, fp64) on the matrices as the kernel sees them
+    Mk = M.to(dtype).double()
+    x = torch.zeros(n, c, h, w, dtype=torch.float64, requires_grad=True)
+    y = torch_oracle.warp_perspective(x, Mk, (H, W), mode="nearest" if nearest else "bilinear")
+    (ref,) = torch.autograd.grad(y, x, go.permute(0, 3, 1, 2))
+    assert ref.abs().max().item() > 0.5
+    tol = 1e-10 if dtype == torch.float64 else 1e-4
+    assert (gs.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item() < tol * (1 + ref.abs().max().item())
+
+
+def test_backward_gather_pixels_kornia_does_not_divide(warp):
+    """|z| <= 1e-8: kornia's convert_points_from_homogeneous leaves the point undivided, so that destination column samples a
+    position unrelated to the projective map.  The gather skips those pixels, warp_bwd_stragglers adds them."""
+    A = torch.tensor([[1.0, 0, 0], [0, 1, 0], [1, 0, -4]], dtype=torch.float64)        # M^-1: z = j - 4
+    M = torch.linalg.inv(A)[None]
+    n, c, h, w, H, W = 1, 4, 12, 16, 10, 9
+    src = torch.randn(n, c, h, w, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    fwd = warp(src.cuda().contiguous(memory_format=torch.channels_last), M, (H, W), channels_last_out=True)
+    want = c_oracle.warp_perspective(src, M, (H, W))
+    assert (fwd.permute(0, 3, 1, 2).cpu() - want).abs().max().item() < 1e-12
+    assert want[..., 4].abs().max().item() > 0.1                     # the undivided column does sample the image
+    go = torch.randn(n, H, W, c, dtype=torch.float64, generator=torch.Generator().manual_seed(2))
+    gs = _bwd_cl(go.cuda(), M, n, c, h, w)
+    assert _last_kernel() == "warp_bwd_gather"
+    ref = c_oracle.warp_perspective_backward(go.permute(0, 3, 1, 2).contiguous(), M, (h, w))
+    assert (gs.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 1e-12
+    only_col = torch.zeros_like(go)
+    only_col[:, :, 4] = go[:, :, 4]
+    assert _bwd_cl(only_col.cuda(), M, n, c, h, w).abs().max().item() > 0.1            # the stragglers carry gradient
+
+
+@pytest.mark.parametrize("C,dtype", [(4, torch.float32), (8, torch.float64), (36, torch.float32), (256, torch.float32),
+                                     (320, torch.float32), (2, torch.float64)])
+def test_backward_gather_channel_counts(warp, C, dtype):
+    """Lane groups of 1 ... 64 lanes per 2x2 texel block, more than 64 chunks (channel groups), odd source sizes."""
+    n, h, w, H, W = 3, 11, 13, 9, 21
+    Ms = wildtrack_mats(None)[:3] @ torch.diag(torch.tensor([12.0, 12.0, 1.0]))
+    Ms = (torch.diag(torch.tensor([0.1, 0.1, 1.0])) @ Ms).double()
+    go = torch.randn(n, H, W, C, generator=torch.Generator().manual_seed(C), dtype=torch.float64)
+    ref = c_oracle.warp_perspective_backward(go.permute(0, 3, 1, 2).contiguous(), Ms.to(dtype).double(), (h, w))
+    assert ref.abs().max().item() > 0.5
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    for env in (None, {"MVDETR_WARP_BWD_HEAVY": "0"}):
+        gs = _bwd_cl(go.to(dtype).cuda(), Ms, n, C, h, w, env=env)
+        assert _last_kernel() == "warp_bwd_gather"
+        assert (gs.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item() < tol * (1 + ref.abs().max().item())
+
+
+def test_stress16_size_forward_and_adjoint(warp):
+    """BASELINE configs[4] at full size: 16 cameras x 256 channels x 135 x 240 -> 120 x 360, both source layouts, against the
+    fp64 C oracle (forward) and through the adjoint identity + a camera subset against the oracle (backward)."""
+    geom = geometry.GEOMETRIES["stress16"]
+    M = wildtrack_mats(None, geom)
+    h, w = geom.Rimg_shape
+    H, W = geom.Rworld_shape
+    C = geom.feat_channels
+    assert (geom.num_cam, C, h, w, H, W) == (16, 256, 135, 240, 120, 360)
+    src = torch.randn(16, C, h, w, generator=torch.Generator().manual_seed(0))
+    ref = c_oracle.warp_perspective(src.double(), M.float().double(), (H, W))
+    a = warp(src.cuda(), M, (H, W))
+    assert _last_kernel() == "warp_fwd<NCHW>"
+    assert (a.cpu().double() - ref).abs().max().item() < 1e-5
+    src_cl = src.cuda().contiguous(memory_format=torch.channels_last)
+    b = warp(src_cl, M, (H, W), channels_last_out=True)
+    assert _last_kernel() == "warp_fwd_cl"
+    assert (b.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item() < 1e-5
+    del a, ref
+    go = torch.randn(16, H, W, C, generator=torch.Generator().manual_seed(1)).cuda()
+    for leaf in (src.cuda().requires_grad_(True), src_cl.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)):
+        out = warp(leaf, M, (H, W), channels_last_out=True)
+        (gs,) = torch.autograd.grad(out, leaf, go)
+        assert _last_kernel() == "warp_bwd_gather"
+        lhs = (go.double() * out.detach().double()).sum().item()
+        rhs = (gs.double() * leaf.detach().double()).sum().item()
+        assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0) + 1e-2
+    cams = [0, 7, 15]
+    refb = c_oracle.warp_perspective_backward(go[cams].permute(0, 3, 1, 2).cpu().double().contiguous(), M[cams].float().double(), (h, w))
+    assert (gs[cams].cpu().double() - refb).abs().max().item() <= 2e-5 * (1 + refb.abs().max().item())
+
+
+def _time_us(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters
+
+
+def test_perf_guard_every_route_within_4x_of_a_copy(warp):
+    """Not a benchmark: a tripwire.  Each forward route at Wildtrack size must stay within 4x of a device copy of the same
+    bytes (r02's accidental default took 16x), the gather backward within 6x."""
+    M = wildtrack_mats(None).cuda()
+    src = torch.randn(7, 128, 90, 160, device="cuda")
+    src_cl = src.contiguous(memory_format=torch.channels_last)
+    nbytes = 4 * 7 * 128 * (90 * 160 + 120 * 360)
+    x = torch.empty(nbytes // 8, device="cuda")
+    y = torch.empty_like(x)
+    copy_us = _time_us(lambda: y.copy_(x))
+    routes = {"NCHW->NCHW": lambda: warp(src, M, (120, 360)),
+              "NCHW->NHWC": lambda: warp(src, M, (120, 360), channels_last_out=True),
+              "NHWC->NHWC": lambda: warp(src_cl, M, (120, 360), channels_last_out=True),
+              "NHWC->NCHW": lambda: warp(src_cl, M, (120, 360))}
+    for name, fn in routes.items():
+        us = _time_us(fn)
+        assert us <= 4.0 * copy_us + 20.0, f"{name}: {us:.0f} us against a {copy_us:.0f} us copy"
+    go = torch.randn(7, 120, 360, 128, device="cuda")
+    us = _time_us(lambda: _bwd_cl(go, M, 7, 128, 90, 160))
+    assert us <= 6.0 * copy_us + 60.0, f"gather backward: {us:.0f} us against a {copy_us:.0f} us copy"

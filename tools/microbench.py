@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--skip-bwd", action="store_true")
+    ap.add_argument("--only", choices=["msda", "warp"], default=None)
     a = ap.parse_args()
     geom = geometry.GEOMETRIES[a.config]
     L = geom.num_cam
@@ -61,6 +62,13 @@ def main():
     fwd_bytes = 4 * B * (S * M * D + 3 * S * M * L * P + S * M * D)
     bwd_bytes = 4 * B * (S * M * D + 2 * S * M * D + 6 * S * M * L * P)
 
+    if a.only != "warp":
+        bench_msda(a, L, H, W, M, D, P, B, S, fwd_bytes, bwd_bytes)
+    if a.only != "msda":
+        bench_warp(a, geom, L, C)
+
+
+def bench_msda(a, L, H, W, M, D, P, B, S, fwd_bytes, bwd_bytes):
     for tag, maker in (("realistic", lambda: encoder_msda_inputs(L, H, W, M, D, P, B=B, seed=0)),
                        ("uniform", lambda: random_msda_inputs(B, [(H, W)] * L, M, D, S, P, seed=1, lo=0, hi=1))):
         value, shapes, lsi, loc, aw = [x.cuda() for x in maker()]
@@ -97,6 +105,9 @@ def main():
                                                        query_levels=(0, n_own))
         report(f"msda_fwd_fused[{n_own} of {L} levels]", time_us(fn, a.iters), own_bytes)
 
+
+
+def bench_warp(a, geom, L, C):
     h, w = geom.Rimg_shape
     Hw, Ww = geom.Rworld_shape
     Ks, Rts = geometry.synthetic_rig(geom, seed=0)
