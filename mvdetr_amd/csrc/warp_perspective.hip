@@ -421,7 +421,8 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
 //        channel chunk of grad_dst (the group reads whole 512-byte pixel rows) and accumulates into the block's four
 //        texels in registers.
 //     grad_src is written once, with plain stores: it need not be zeroed, and each grad_dst row is read ~2.25 times
-//     (once per block its footprint touches), mostly from L2.
+//     (once per block its footprint touches), mostly from L2.  One difference from a scatter: a hit adds 0 * g to the
+//     block texels its footprint misses, so a NON-FINITE upstream gradient spreads to the other texels of the 2 x 2 block.
 //   * warp_bwd_stragglers: kornia divides by z only where |z| > 1e-8 (convert_points_from_homogeneous); a destination
 //     pixel with |z| <= 1e-8 samples a position unrelated to the projective map, so no scan finds it.  The gather skips
 //     such pixels and this kernel (one lane per destination pixel, returns at once unless |z| <= 1e-8) scatters them
@@ -742,24 +743,26 @@ __device__ __forceinline__ void warp_gather_rounds(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // stream st takes hits st, st + S, ...: WARP_GU of them in flight
-            for (int q = st; q < nhit; q += WARP_GU * S) {
+            // stream st takes hits st, st + S, ...: WARP_GU of them in flight.  (q0 + u * S < nhit is wave-uniform: whole
+            // steps are skipped with a scalar branch; the one stream that runs out a hit early gets zero weights.)
+            for (int q0 = 0; q0 < nhit; q0 += WARP_GU * S) {
                 Pack<T, VEC> g[WARP_GU];
 #pragma unroll
                 for (int u = 0; u < WARP_GU; ++u) {           // the loads first (only the offsets are read here) ...
-                    const int off = mine[min(q + u * S, nhit - 1)].pix;
+                    const int off = mine[min(q0 + u * S + st, nhit - 1)].pix;      // (clamped: branch-free, so they overlap)
                     g[u] = has_ch ? Pack<T, VEC>::load(gchunk + off) : Pack<T, VEC>::zero();
                 }
 #pragma unroll
-                for (int u = 0; u < WARP_GU; ++u) {           // ... then weights and masks, re-read from LDS
-                    const int qq = q + u * S;
-                    const Rec rr = mine[min(qq, nhit - 1)];
-                    const int mask = qq < nhit ? rr.mask : 0;
+                for (int u = 0; u < WARP_GU; ++u) {           // ... then the weights, re-read from LDS
+                    if (q0 + u * S < nhit) {
+                        const int qq = q0 + u * S + st;
+                        const Rec rr = mine[min(qq, nhit - 1)];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const bool on = (mask >> t) & 1;
+                        for (int t = 0; t < 4; ++t) {
+                            const T wt = qq < nhit ? rr.w[t] : T(0);       // (texels the footprint misses have weight 0)
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) acc[t][v] = on ? acc[t][v] + rr.w[t] * g[u].v[v] : acc[t][v];
+                            for (int v = 0; v < VEC; ++v) acc[t][v] += wt * g[u].v[v];
+                        }
                     }
                 }
             }
