@@ -54,6 +54,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
 bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16, int ql0, int ql1)
 {
     if (!aligned16 || P != TILE_P || L > TILE_MAX_LEVELS || B < 1) return false;
+    // the LDS-DMA window copies (msda_forward_group.hip, msda_backward_sampling.hip) address one batch element's value
+    // tokens through a 32-bit buffer descriptor whose out-of-range sentinel is offset 2^31: a per-batch value tensor of
+    // 2 GiB or more would alias it.  Such calls take the gather / lane-group kernels (64-bit addressing).
+    if ((int64_t)S * M * D * 4 >= 0x7fffffffLL) return false;
     const bool all_levels = ql0 == 0 && ql1 == L;
     if (ql0 < 0 || ql1 <= ql0 || ql1 > L || (all_levels ? Lq != S : Lq > S)) return false;
     return (D == 16 && M % 2 == 0) || D == 32;
@@ -112,8 +116,6 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
     const SamplingLayout lay = plain_layout(M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P);     // [.., Lq, M, L, P(, 2)]
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
-    if (msda_quad_supported(M, D, L) && !narrow_slices())
-        return msda_forward_quad(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
     if (msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
     return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out, local_hits);
@@ -145,9 +147,6 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     // A query-sharded call (a rank's own cameras as queries, mvdetr_amd/dist.py) has too few query levels per
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
-    if (all_levels && msda_quad_supported(M, D, L) && !narrow_slices())
-        return msda_forward_quad(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
-                                 M, D, L, out);
     if (all_levels && msda_group_supported(D, L) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
                                   M, D, L, out);

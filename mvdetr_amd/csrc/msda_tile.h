@@ -76,12 +76,6 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out,
                        const int *local_hits = nullptr);
 
-// camera-grouped forward with a quad of lanes per (cell, head) (msda_forward_quad.hip); same contract as the group kernel
-bool msda_quad_supported(int M, int D, int L);
-int msda_forward_quad(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi, const float *off,
-                      const float *logit, const float *ref, int64_t ref_bstride, int fused, SamplingLayout lay, int B,
-                      int S, int M, int D, int L, float *out, const int *local_hits = nullptr);
-
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
 // scalar registers).
 template <typename Cfg>

@@ -135,7 +135,7 @@ class QueryShardedFusion:
         wf, own = self.wf, self.own_slice(h, w)
         B = src_own.shape[0]
         ref = wf.encoder.reference_points[own].unsqueeze(0).expand(B, -1, -1, -1, -1)
-        shared = wf.encoder.reference_shared
+        shared = wf.encoder.shared_reference()
         if shared is not None:
             shared = shared[:, own].unsqueeze(0)                 # level-major [1, L, own queries, 2]
         return wf.encoder.layers[i](src_own, wf.level_pos(h, w)[:, own], ref, wf.spatial_shapes,

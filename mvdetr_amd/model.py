@@ -116,6 +116,10 @@ class MVDeTr(nn.Module):
         bottleneck_dim = geom.feat_channels if bottleneck_dim is None else bottleneck_dim
         # image pixel -> reduced world grid, fp64 (mvdetr.py:82-95)
         self.register_buffer("proj_mats", torch.from_numpy(geometry.build_proj_mats(geom, Ks, Rts, z)), persistent=False)
+        # host copy for the per-frame composition: the buffer above follows .to(device) (it is part of the reference's
+        # attribute set, mvdetr.py:95), and reading it back every forward would be a full-stream sync per frame
+        self._proj_mats_host, self._proj_host_key = None, None
+        self._proj_pinned, self._proj_pinned_event = None, None
         if arch not in ("resnet18", "resnet50"):
             raise ValueError("trunks: resnet18 (the reference's default, mvdetr.py:102-105) or resnet50 (BASELINE configs[3]; "
                              "resnet.py:244); vgg11 is not provided")
@@ -149,10 +153,29 @@ class MVDeTr(nn.Module):
                 if isinstance(m, nn.Conv2d) and m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def frame_proj_mats(self, M):
+    def frame_proj_mats(self, M, device=None):
         """[B*N,3,3] fp32 reduced world grid <- feature pixel, composed on the host in fp32 exactly like
-        mvdetr.py:155-161 (M is the dataloader's augmentation matrix and lives on the CPU there)."""
-        return geometry.compose_frame_proj_mats(self.proj_mats.cpu(), M.cpu(), self.img_reduce)
+        mvdetr.py:155-161 (M is the dataloader's augmentation matrix and lives on the CPU there).  With ``device`` the
+        result is uploaded from a pinned staging buffer with a non-blocking copy: nothing in a frame waits for the GPU,
+        so the host can queue frame k+1 behind frame k (the reference composes on the CPU and does a pageable
+        ``.to(device)`` every forward, mvdetr.py:194)."""
+        pm = self.proj_mats
+        key = (id(pm), pm._version)                                       # refreshed (one sync) after .to(device) / in-place edits
+        if key != self._proj_host_key:
+            self._proj_mats_host, self._proj_host_key = pm.detach().cpu().clone(), key
+        proj = geometry.compose_frame_proj_mats(self._proj_mats_host, M.cpu(), self.img_reduce)
+        if device is None or torch.device(device).type == "cpu":
+            return proj
+        if self._proj_pinned is None or self._proj_pinned.shape != proj.shape:
+            self._proj_pinned = torch.empty_like(proj).pin_memory()
+            self._proj_pinned_event = None
+        if self._proj_pinned_event is not None:
+            self._proj_pinned_event.synchronize()                         # the previous frame's upload has left the buffer
+        self._proj_pinned.copy_(proj)
+        out = self._proj_pinned.to(device, non_blocking=True)
+        self._proj_pinned_event = torch.cuda.Event()
+        self._proj_pinned_event.record(torch.cuda.current_stream(device))
+        return out
 
     def features(self, imgs):
         B, N, C, H, W = imgs.shape
@@ -163,13 +186,13 @@ class MVDeTr(nn.Module):
 
     def forward(self, imgs, M, visualize=False):
         B, N = imgs.shape[:2]
-        proj = self.frame_proj_mats(M)
+        proj = self.frame_proj_mats(M, imgs.device)
         feat = self.features(imgs)                                         # [B*N, C, h, w]
         imgs_heatmap, imgs_offset, imgs_wh = self.img_heatmap(feat), self.img_offset(feat), self.img_wh(feat)
         H, W = self.Rworld_shape
         C = feat.shape[1]
         nhwc = self.channels_last and self.world_feat_arch == "deform_trans"
-        world = warp_perspective(feat, proj.to(feat.device, non_blocking=True), (H, W), channels_last_out=nhwc)
+        world = warp_perspective(feat, proj, (H, W), channels_last_out=nhwc)
         world = world.view(B, N, H, W, C) if nhwc else world.view(B, N, C, H, W)
         world = self.world_feat(world)
         return (self.world_heatmap(world), self.world_offset(world)), (imgs_heatmap, imgs_offset, imgs_wh)

@@ -30,26 +30,31 @@ from .ops.modules import MSDeformAttn
 
 
 def create_pos_embedding(img_size, num_pos_feats=64, temperature=10000, normalize=True, scale=None):
-    """Sine position embedding [1, 2*num_pos_feats, H, W] (DETR style, normalised to 2*pi)."""
-    if scale is not None and normalize is False:
+    """Sine position embedding ``[1, 2 * num_pos_feats, H, W]`` (same signature and values as trans_world_feat.py:15-37).
+
+    Channel ``k < F`` (F = num_pos_feats) encodes the row, channel ``F + k`` the column of a cell:
+    ``sin(c / T**(2 * (k // 2) / F))`` for even k and ``cos`` of the same angle for odd k, where c counts cells from 1
+    and, when ``normalize``, is mapped to ``(0, scale]`` by ``c / (size + 1e-6) * scale`` (scale = 2 pi by default).
+    Built from two small per-axis tables ([H, F] and [W, F]) that are broadcast over the other axis.
+    """
+    if scale is not None and not normalize:
         raise ValueError("normalize should be True if scale is passed")
-    if scale is None:
-        scale = 2 * math.pi
     H, W = int(img_size[0]), int(img_size[1])
-    ones = torch.ones([1, H, W])
-    y_embed = ones.cumsum(1, dtype=torch.float32)
-    x_embed = ones.cumsum(2, dtype=torch.float32)
-    if normalize:
-        eps = 1e-6
-        y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
-        x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
-    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
-    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
-    pos_x = x_embed[:, :, :, None] / dim_t
-    pos_y = y_embed[:, :, :, None] / dim_t
-    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
-    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
-    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+    F_ = int(num_pos_feats)
+    k = torch.arange(F_, dtype=torch.float32)
+    period = temperature ** (2 * (k // 2) / F_)                 # [F]; pairs (2m, 2m + 1) share a period
+    odd = (torch.arange(F_) % 2).bool()
+
+    def axis_table(size):
+        c = torch.arange(1, size + 1, dtype=torch.float32)
+        if normalize:
+            c = c / (size + 1e-6) * (2 * math.pi if scale is None else scale)
+        angle = c[:, None] / period                             # [size, F]
+        return torch.where(odd, angle.cos(), angle.sin())
+
+    rows = axis_table(H).t()[:, :, None].expand(F_, H, W)       # [F, H, W]: constant along x
+    cols = axis_table(W).t()[:, None, :].expand(F_, H, W)       # [F, H, W]: constant along y
+    return torch.cat((rows, cols), 0)[None].contiguous()
 
 
 class DeformableTransformerEncoderLayer(nn.Module):
@@ -99,14 +104,27 @@ class DeformableTransformerEncoder(nn.Module):
         self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
         self.num_layers = num_layers
         self.register_buffer("reference_shared", None, persistent=False)
+        self._reference_key = None
         if reference_points is not None:
             self.register_buffer("reference_points", reference_points, persistent=False)
-            # MVDeTr's map repeats one point n_points times (mvdetr.py:49-58 with all heights 0): tell the attention
-            # modules so (level-major [L, Lq, 2]; they would otherwise test it themselves, a device sync per new view)
-            if bool((reference_points == reference_points[..., :1, :]).all()):
-                self.reference_shared = reference_points[..., 0, :].transpose(0, 1).contiguous()
+            self.shared_reference()
         else:
             self.reference_points = None
+
+    def shared_reference(self):
+        """``[L, Lq, 2]`` when every (query, level) holds ONE point repeated n_points times -- MVDeTr's map with all
+        heights 0, mvdetr.py:49-58 -- else None.  Derived from ``reference_points`` and re-derived whenever that buffer is
+        replaced or written in place (keyed by tensor identity and ``_version``: a comparison per forward, no device
+        sync unless the key moved), so the fused path can never sample a stale copy of the map."""
+        rp = self.reference_points
+        if rp is None:
+            return None
+        key = (id(rp), rp._version)
+        if key != self._reference_key:
+            same = bool((rp == rp[..., :1, :]).all())
+            self.reference_shared = rp[..., 0, :].transpose(0, 1).contiguous() if same else None
+            self._reference_key = key
+        return self.reference_shared
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios=None, pos=None, padding_mask=None):
         if self.reference_points is None:
@@ -114,7 +132,8 @@ class DeformableTransformerEncoder(nn.Module):
                              "default of Deformable-DETR is not part of this contract "
                              "(ms_deform_attn.py:104-107)")
         ref = self.reference_points.unsqueeze(0).expand(src.shape[0], -1, -1, -1, -1)
-        shared = None if self.reference_shared is None else self.reference_shared.unsqueeze(0)
+        shared = self.shared_reference()
+        shared = None if shared is None else shared.unsqueeze(0)
         out, query = src, None
         for i, layer in enumerate(self.layers):
             if pos is not None and i + 1 < self.num_layers:

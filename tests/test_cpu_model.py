@@ -57,3 +57,19 @@ def test_resnet50_trunk_is_wired():
     assert wh.shape == (1, 1, 24, 72) and ih.shape == (3, 1, 18, 32) and torch.isfinite(wh).all()
     with pytest.raises(ValueError):
         build_model("mini", arch="vgg11")
+
+
+def test_shared_reference_follows_the_reference_points_buffer():
+    """the encoder's one-point-per-(query, level) shortcut must be re-derived when reference_points is replaced
+    or written in place -- the fused path would otherwise keep sampling from a stale map."""
+    import torch
+    from mvdetr_amd.world_feat import DeformableTransformerEncoder, DeformableTransformerEncoderLayer
+    ref = torch.rand(12, 3, 1, 2).repeat(1, 1, 4, 1)                       # [Lq, L, P, 2], one point repeated P times
+    enc = DeformableTransformerEncoder(DeformableTransformerEncoderLayer(16, 32, 0.0, 3, 2, 4), 1, ref.clone())
+    a = enc.shared_reference()
+    assert a.shape == (3, 12, 2) and torch.equal(a, ref[..., 0, :].transpose(0, 1))
+    assert enc.shared_reference() is a                                     # cached while the buffer is untouched
+    enc.reference_points.mul_(0.5)                                         # in-place edit: same tensor, new version
+    assert torch.equal(enc.shared_reference(), 0.5 * ref[..., 0, :].transpose(0, 1))
+    enc.reference_points = torch.rand(12, 3, 4, 2)                         # replaced by a map with P distinct points
+    assert enc.shared_reference() is None

@@ -82,6 +82,17 @@ def test_msda_module_restatement():
 
 
 # ---- (6) position embedding ------------------------------------------------------------------------
+def test_product_pos_embedding_equals_the_reference_bit_for_bit():
+    """mvdetr_amd.world_feat.create_pos_embedding (written from the formula) against the reference's output."""
+    from mvdetr_amd.world_feat import create_pos_embedding
+    g = load_golden("pos_embedding.npz")
+    assert torch.equal(create_pos_embedding((6, 9), 8), t(g["small"]))
+    assert torch.equal(create_pos_embedding((60, 180), 64), torch_oracle.create_pos_embedding((60, 180), 64))
+    assert create_pos_embedding((5, 7), 6, normalize=False).shape == (1, 12, 5, 7)
+    with pytest.raises(ValueError):
+        create_pos_embedding((5, 7), 6, normalize=False, scale=1.0)
+
+
 def test_pos_embedding():
     g = load_golden("pos_embedding.npz")
     assert torch.equal(torch_oracle.create_pos_embedding((6, 9), 8), t(g["small"]))

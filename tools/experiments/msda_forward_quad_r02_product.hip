@@ -1,3 +1,6 @@
+// EXPERIMENT, not part of libmvdetr_ops.so.  Round 2 shipped this file inside the library behind MVDETR_MSDA_QUAD=1 without a
+// test that set the variable; it is parity-green but slower than msda_fwd_group (152 / 170 us against
+// 128 / 139 us), so it was taken out of the product.  It builds against mvdetr_amd/csrc/{common.h,msda_tile.h}.
 // Multi-scale deformable attention forward, camera-grouped "quad" kernel -- gfx950 (MI355X).
 //
 // Same job as msda_forward_group.hip -- one workgroup owns a (6 x 16 cell tile, 128-byte slice) and walks all
