@@ -16,6 +16,11 @@ Prints ONE JSON line (rank 0):
                    here with HIP events on the launching stream, against the 8 TB/s HBM peak;
                    `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes
                    (profiles/*_traffic.json), null when that file is absent
+  roofline_warp / roofline_warp_bwd / roofline_msda_bwd
+                   the other kernels SURVEY 8d names, same accounting (4*N*C*(h*w + H*W) bytes for the warp and its
+                   gradient; 4*(Lq*M*D + 2*S*M*D + 6*Lq*M*L*P) for the MSDA backward), HIP events over 12 launches each,
+                   measured on rank 0 after the timed region; roofline.code_object = registers / scratch (spill) bytes per
+                   lane / static LDS of the forward instantiation that ran, read from the code object
   cpu_baseline     the oracle (the reference's CPU formulation: grid_sample-based deformable
                    attention + kornia-semantics warp + the same trunk) timed on this box's host cores:
                    a thread sweep (1, physical/2, physical) over the two hot ops on a bounded sample
@@ -36,6 +41,7 @@ import glob
 import json
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -61,6 +67,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="frames per step per rank (dp mode; the reference only supports 1)")
     ap.add_argument("--augment", action="store_true", help="random affine augmentation matrices instead of identity")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-rooflines", action="store_true",
+                    help="skip roofline_warp / roofline_warp_bwd / roofline_msda_bwd (measured after the timed region)")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="keep hipBLASLt's default solution per GEMM instead of PyTorch TunableOp's measured pick")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -142,6 +150,93 @@ class KernelTimer:
             return None, 0, None
         ts = [a.elapsed_time(b) * 1e3 for a, b, _ in self.events]
         return sum(ts) / len(ts), len(ts), sum(n for _, _, n in self.events) / len(self.events)
+
+
+def time_launches(fn, launches=12, warmup=3):
+    """Average / min duration in us of `fn` (one device call) over `launches` launches, each bracketed by HIP events on
+    the current stream -- the stream the kernels are launched on."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ts = [e0.elapsed_time(e1) * 1e3 for e0, e1 in ev]
+    return sum(ts) / len(ts), min(ts)
+
+
+def roofline_entry(kernel, us, us_min, nbytes, launches, what, extra=None):
+    ach = nbytes / (us * 1e-6) / 1e9
+    d = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(nbytes),
+         "avg_launch_us": round(us, 2), "min_launch_us": round(us_min, 2), "launches_timed": launches, "what": what}
+    d.update(extra or {})
+    return d
+
+
+def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
+    """SURVEY 8d also asks for the warp and the MSDA backward: the other kernels of the path, on the same shapes and the
+    same locality-realistic inputs, HIP events over `launches` launches each (rank 0, after the timed region)."""
+    from helpers import encoder_msda_inputs
+    from mvdetr_amd.ops import warp as warp_mod
+    from mvdetr_amd.ops import warp_perspective
+    out = {}
+    N, C = geom.num_cam, feat.shape[1]
+    h, w = feat.shape[-2:]
+    H, W = model.Rworld_shape
+    wbytes = 4 * N * C * (h * w + H * W)                                  # SURVEY 8d: 4 N C (h w + H W)
+    f1 = feat[:N]
+    p1 = proj[:N]
+    with torch.no_grad():
+        nhwc = model.channels_last
+        us, mn = time_launches(lambda: warp_perspective(f1, p1, (H, W), channels_last_out=nhwc), launches)
+        out["roofline_warp"] = roofline_entry(
+            warp_mod.last_kernel(), us, mn, wbytes, launches,
+            "the warp as the model runs it: channels_last trunk features read in place -> token layout [N,H,W,C]"
+            if nhwc else "NCHW features -> NCHW world features")
+        f_nchw = f1.contiguous(memory_format=torch.contiguous_format)
+        us, mn = time_launches(lambda: warp_perspective(f_nchw, p1, (H, W)), launches)
+        out["roofline_warp"]["nchw_to_nchw"] = {
+            "kernel": warp_mod.last_kernel(), "avg_launch_us": round(us, 2), "frac": round(wbytes / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+            "what": "the literal layouts of kornia.warp_perspective at mvdetr.py:194-195 (NCHW source and destination)"}
+        go = torch.randn(N, H, W, C, device=feat.device)
+        gs = torch.empty(N, h, w, C, device=feat.device)
+        pm = p1.to(device=feat.device, dtype=torch.float32).contiguous()
+        us, mn = time_launches(lambda: warp_mod._launch("backward", go, pm, N, C, h, w, H, W, 3, gs), launches)
+        out["roofline_warp_bwd"] = roofline_entry(
+            warp_mod.last_kernel(), us, mn, wbytes, launches,
+            "gradient of the warp w.r.t. the features, channel-last on both sides (C ABI entry: candidate scans + gather + "
+            "stragglers; deterministic, no atomics)")
+        del go, gs
+        # MSDA backward at this configuration's encoder shape, SURVEY 8d's input (bias grid + N(0, 1 px) offsets)
+        wf = model.world_feat
+        hh, ww = (int(x) for x in wf.spatial_shapes[0])
+        M_, D_ = 8, wf.hidden_dim // 8
+        value, shapes, lsi, loc, aw = [x.to(feat.device) for x in encoder_msda_inputs(N, hh, ww, M_, D_, 4, seed=0)]
+        S = N * hh * ww
+        gout = torch.randn(1, S, M_ * D_, device=feat.device)
+        bbytes = 4 * (S * M_ * D_ + 2 * S * M_ * D_ + 6 * S * M_ * N * 4)   # SURVEY 8d: 4 (Lq M D + 2 S M D + 6 Lq M L P)
+        us, mn = time_launches(lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, gout, 64), launches)
+        out["roofline_msda_bwd"] = roofline_entry(
+            "msda_bwd_value_win + msda_bwd_sampling_resident (+ memset of grad_value)" if (D_ == 16 and N <= 7)
+            else "msda_bwd_value_win + msda_bwd_sampling_tile (+ memset of grad_value)", us, mn, bbytes, launches,
+            "MultiScaleDeformableAttention.ms_deform_attn_backward (public contract), SURVEY 8d's locality-realistic input: "
+            "bias grid + N(0, 1 px) offsets, softmax(N(0,1)) weights")
+    return out
+
+
+def write_tunableop_results(tun, path):
+    """The in-memory TunableOp results of this process in the CSV format torch.cuda.tunable.read_file() takes
+    (validator lines, then op signature, parameter signature, solution, time)."""
+    lines = [f"Validator,{k},{v}" for k, v in tun.get_validators()]
+    lines += [",".join(str(x) for x in row) for row in tun.get_results()]
+    tmp = path + ".tmp"
+    with open(tmp, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    os.replace(tmp, path)
 
 
 def load_traffic():
@@ -236,7 +331,6 @@ def main():
         # shape once (during the warm-up steps) and keeps the fastest; same arithmetic type, nothing is written to disk.
         # All-or-nothing: if any step of the set-up fails, tuning is switched off again and the line says so.
         try:
-            import tempfile
             tun = torch.cuda.tunable
             tun.set_filename(os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_{os.getpid()}.csv"))
             if hasattr(tun, "write_file_on_exit"):         # (not in every torch build; the results file is scratch anyway)
@@ -286,6 +380,32 @@ def main():
                 return model(imgs, M)
         frames_per_step, scaling = world * Bf, "weak"
 
+    tuning_shared = None
+    if world > 1 and gemm_tuning:
+        # rank 0 warms up first: TunableOp's measured GEMM picks go to ONE results file and MIOpen's find results to its
+        # user database; the other ranks then read both instead of each spending its warm-up measuring the same shapes.
+        # Every rank runs the same barrier sequence whatever fails in between.
+        tun = torch.cuda.tunable
+        shared = os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_shared_{os.environ.get('MASTER_PORT', '0')}.csv")
+        tuning_shared = True
+        if rank == 0:
+            try:
+                for _ in range(max(a.warmup, 1)):
+                    step()
+                torch.cuda.synchronize()
+                write_tunableop_results(tun, shared)
+            except Exception as ex:                # pragma: no cover
+                tuning_shared = False
+                print(f"[bench] rank 0: writing the shared TunableOp results failed ({ex}); tuning per rank", file=sys.stderr)
+        torch.distributed.barrier()
+        if rank != 0:
+            try:
+                if not (os.path.exists(shared) and tun.read_file(shared)):
+                    raise RuntimeError("no usable results file from rank 0")
+                tun.tuning_enable(False)
+            except Exception as ex:                # pragma: no cover
+                tuning_shared = False
+                print(f"[bench] rank {rank}: reading the shared TunableOp results failed ({ex}); tuning here", file=sys.stderr)
     for _ in range(a.warmup):
         step()
     if world > 1:
@@ -302,18 +422,29 @@ def main():
     timer.enabled = False
     k_us, k_n, k_bytes = timer.average_us()
     impl = MSDA.last_forward_kernel()
+    fwd_resources = MSDA.last_forward_resources()          # registers / scratch (spill) bytes per lane / static LDS of that instantiation
     # ranks the collective library actually connected (one process may be all there is)
     seen = torch.ones(1, device=dev)
     if world > 1:
         torch.distributed.all_reduce(seen)
     n_ranks = int(seen.item())
+    # where every rank ran: (rank, device index, devices visible, device uuid-ish name, host)
+    import socket
+    me = {"rank": rank, "device": dev.index, "gpus_visible": torch.cuda.device_count(),
+          "device_name": torch.cuda.get_device_name(dev), "host": socket.gethostname(),
+          "bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)}
+    placement = [me]
+    if world > 1:
+        placement = [None] * world
+        torch.distributed.all_gather_object(placement, me)
+    distinct_devices = len({(p["host"], p["device"]) for p in placement})
 
     # ---- the hot path alone (warp + shadow transformer), same inputs ------------------------------------
     hot_ms = None
     if a.parallel == "dp":
         with torch.no_grad():
             feat = model.features(imgs)
-            proj = model.frame_proj_mats(M).to(dev)
+            proj = model.frame_proj_mats(M, dev)
             for _ in range(3):
                 model.hot_path(feat, proj)
             torch.cuda.synchronize()
@@ -356,8 +487,9 @@ def main():
     res = {
         "metric": "multiview frames/s (7-cam Wildtrack) + MSDeformAttn HBM GB/s vs roofline",
         "value": round(frames_per_step * a.steps / elapsed, 3), "unit": "frames/s",
-        "n_gpus": n_ranks, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
+        "n_gpus": min(n_ranks, distinct_devices), "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": scaling if distinct_devices >= n_ranks else None,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{a.config} {N}-cam frame, --world_feat deform_trans, {a.arch} trunk: "
                                f"{N}x3x{Hi}x{Wi} -> {geom.feat_channels}-ch world feat {geom.Rworld_shape[0]}x{geom.Rworld_shape[1]} "
@@ -365,13 +497,17 @@ def main():
                    "frames_per_step": frames_per_step, "batch_per_rank": Bf, "parallelism": f"{a.parallel}{world}" + (f"-{a.encoder}" if a.parallel == "views" and world > 1 else ""),
                    "augment": bool(a.augment), "gemm_tuning": gemm_tuning,
                    "backend": (os.environ.get("MVDETR_DIST_BACKEND") or "nccl (RCCL)") if world > 1 else None,
-                   "gpus_visible": torch.cuda.device_count(),
+                   "gpus_visible": torch.cuda.device_count(), "ranks": n_ranks, "distinct_devices": distinct_devices,
+                   "oversubscribed": distinct_devices < n_ranks,
+                   "rank_placement": [{k: p[k] for k in ("rank", "device", "gpus_visible", "bus_id")} for p in placement],
+                   "gemm_tuning_shared_from_rank0": tuning_shared,
                    "weights": "seeded random" + (f"; sampling-offset / attention projections perturbed (seeded) to ~{offset_std:g} px offset std, "
                                                  "SURVEY 8d's locality-realistic input" if offset_std else "; reference init (zero offset weights)")},
         "roofline": {"bound": "hbm", "kernel": impl, "achieved": round(achieved, 1) if achieved else None,
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4) if achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": round(k_us, 2) if k_us else None, "launches_timed": k_n,
+                     "code_object": fwd_resources,
                      "input": (f"learned-like offsets: bias grid + ~N(0, {offset_std:g} px) (SURVEY 8d)" if offset_std
                                else "reference init: constant bias-grid offsets"),
                      "init_weights": ({"avg_launch_us": round(init_us, 2), "frac": round(alg_bytes / (init_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
@@ -381,6 +517,8 @@ def main():
                      "frames_per_s": round(1e3 / hot_ms, 1) if hot_ms else None,
                      "what": "warp_perspective + DeformTransWorldFeat (3 x MSDeformAttn), features resident"},
     }
+    if a.parallel == "dp" and not a.no_kernel_rooflines and hasattr(model.world_feat, "encoder"):
+        res.update(other_kernel_rooflines(model, geom, feat, proj, MSDA))
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(model, imgs[:1].cpu(), model.frame_proj_mats(M[:1]), a.cpu_budget_s)
     else:

@@ -199,6 +199,10 @@ const char *mvdetr_msda_last_forward_impl(void);
 /* Name of the kernel that call launched ("msda_fwd_group[LDS-DMA windows]", "msda_fwd_tile", "msda_fwd_gather", ...). */
 const char *mvdetr_msda_last_forward_kernel(void);
 
+/* What the code object records for that kernel instantiation (hipFuncGetAttributes): registers per lane, scratch bytes per
+ * lane (non-zero = the instantiation spills), static LDS bytes.  Returns 0 (and -1 in the outputs) when unknown. */
+int mvdetr_msda_last_forward_resources(int *num_regs, int *scratch_bytes_per_lane, int *static_lds_bytes);
+
 /* Name of the kernel the last warp call of this process launched (any thread: autograd runs backwards on its own) ("warp_fwd_cl", "warp_fwd<NCHW>", "warp_bwd_gather",
  * ...): one name per layout route, asserted by tests/test_warp_gpu.py.  Static storage; never NULL. */
 const char *mvdetr_warp_last_kernel(void);

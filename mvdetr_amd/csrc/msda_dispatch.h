@@ -8,7 +8,19 @@ namespace mvdetr {
 enum class MsdaFwdImpl { Gather, Tile };
 
 // name of the kernel the last forward on this thread launched (bench / tests only; set by the launchers)
-void msda_note_forward_kernel(const char *name);
+// what the code object says about a kernel (hipFuncGetAttributes): registers per lane, scratch (spill) bytes per lane,
+// static LDS bytes.  Queried once per instantiation by the launchers and reported through
+// mvdetr_msda_last_forward_resources().
+struct KernelResources {
+    int num_regs, scratch_bytes, static_lds_bytes;
+};
+inline KernelResources kernel_resources(const void *func)
+{
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, func) != hipSuccess) return KernelResources{-1, -1, -1};
+    return KernelResources{at.numRegs, (int)at.localSizeBytes, (int)at.sharedSizeBytes};
+}
+void msda_note_forward_kernel(const char *name, const KernelResources *res = nullptr);
 
 // fp32 LDS-tiled encoder kernel (msda_forward_tile.hip).  Only valid when
 // msda_fwd_choose_impl() returned Tile.

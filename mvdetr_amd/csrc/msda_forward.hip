@@ -96,7 +96,12 @@ template int msda_forward_gather<double>(hipStream_t, const double *, const int6
 
 static thread_local const char *g_last_impl = "none";
 static thread_local const char *g_last_kernel = "none";
-void msda_note_forward_kernel(const char *name) { g_last_kernel = name; }
+static thread_local KernelResources g_last_resources = {-1, -1, -1};
+void msda_note_forward_kernel(const char *name, const KernelResources *res)
+{
+    g_last_kernel = name;
+    g_last_resources = res ? *res : KernelResources{-1, -1, -1};
+}
 
 static bool bad_dims(int B, int S, int M, int D, int L, int Lq, int P)
 {
@@ -132,7 +137,7 @@ static int forward_entry(void *stream, const T *value, const int64_t *shapes, co
         }
     }
     g_last_impl = "gather";
-    g_last_kernel = "msda_fwd_gather";
+    msda_note_forward_kernel("msda_fwd_gather");
     return msda_forward_gather<T>(st, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out);
 }
 
@@ -143,6 +148,14 @@ extern "C" {
 int mvdetr_ops_abi_version(void) { return MVDETR_OPS_ABI_VERSION; }
 
 const char *mvdetr_msda_last_forward_impl(void) { return mvdetr::g_last_impl; }
+int mvdetr_msda_last_forward_resources(int *num_regs, int *scratch_bytes_per_lane, int *static_lds_bytes)
+{
+    const mvdetr::KernelResources r = mvdetr::g_last_resources;
+    if (num_regs) *num_regs = r.num_regs;
+    if (scratch_bytes_per_lane) *scratch_bytes_per_lane = r.scratch_bytes;
+    if (static_lds_bytes) *static_lds_bytes = r.static_lds_bytes;
+    return r.num_regs >= 0;
+}
 const char *mvdetr_msda_last_forward_kernel(void) { return mvdetr::g_last_kernel; }
 
 int mvdetr_msda_set_forward_impl(int impl)

@@ -360,8 +360,9 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
     }();
+    static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>));
     msda_note_forward_kernel(DMA ? (SPLIT > 1 ? "msda_fwd_group[camera-split, LDS-DMA windows]" : "msda_fwd_group[LDS-DMA windows]")
-                                 : (SPLIT > 1 ? "msda_fwd_group[camera-split]" : "msda_fwd_group"));
+                                 : (SPLIT > 1 ? "msda_fwd_group[camera-split]" : "msda_fwd_group"), &res);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits);
     return (int)hipGetLastError();
 }

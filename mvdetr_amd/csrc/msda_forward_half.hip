@@ -13,7 +13,8 @@
 
 namespace mvdetr {
 
-void msda_note_forward_kernel(const char *name);
+struct KernelResources;
+void msda_note_forward_kernel(const char *name, const KernelResources *res = nullptr);
 
 struct F16 {
     static __device__ __forceinline__ float up(uint16_t h)

@@ -81,7 +81,8 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
         int n = cus * per_cu;
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
     }();
-    msda_note_forward_kernel("msda_fwd_tile");
+    static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>));
+    msda_note_forward_kernel("msda_fwd_tile", &res);
     hipLaunchKernelGGL((msda_fwd_tile<Cfg, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,
                        st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out, local_hits);
     return (int)hipGetLastError();

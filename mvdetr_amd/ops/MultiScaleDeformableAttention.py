@@ -228,6 +228,17 @@ def last_forward_kernel() -> str:
     return _lib.lib().mvdetr_msda_last_forward_kernel().decode()
 
 
+def last_forward_resources():
+    """What the code object records for the kernel instantiation the last forward on this thread launched:
+    ``{"num_regs", "scratch_bytes_per_lane", "static_lds_bytes"}`` (hipFuncGetAttributes; scratch > 0 = it spills), or
+    None when the launcher does not report it (bench/tests only)."""
+    import ctypes
+    r, s_, l_ = ctypes.c_int(-1), ctypes.c_int(-1), ctypes.c_int(-1)
+    if not _lib.lib().mvdetr_msda_last_forward_resources(ctypes.byref(r), ctypes.byref(s_), ctypes.byref(l_)):
+        return None
+    return {"num_regs": r.value, "scratch_bytes_per_lane": s_.value, "static_lds_bytes": l_.value}
+
+
 _IMPLS = {"auto": 0, "gather": 1, "tile": 2}
 
 

@@ -172,3 +172,76 @@ def test_query_sharded_fusion_world2(num_views):
         p.join(timeout=60)
     for rank, ok, msg in results:
         assert ok, f"rank {rank}: {msg}"
+
+
+# ---- world size 8 through real collectives (only world 2 had ever run them) -----------------------
+def _run_world(target, world, args, timeout=300):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, msg in sorted(results):
+        assert ok, f"rank {rank}: {msg}"
+    return results
+
+
+@pytest.mark.parametrize("num_views", [7, 16])
+def test_view_sharded_all_gather_world8(num_views):
+    """7 views over 8 ranks (rank 7 idle: a zero-length shard in the padded all-gather) and 16 views, 2 per rank."""
+    _run_world(_worker, 8, (num_views,))
+
+
+@pytest.mark.parametrize("num_views", [7, 16])
+def test_query_sharded_fusion_world8(num_views):
+    _run_world(_sharded_worker, 8, (num_views,))
+
+
+def _frame_worker(rank, world, port, num_views, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), MVDETR_HOST_THREADS="1", OMP_NUM_THREADS="1")
+    try:
+        import dataclasses
+        from mvdetr_amd import geometry
+        from mvdetr_amd.model import build_model
+        torch.set_num_threads(1)
+        mdist.init_from_env()
+        name = f"mini{num_views}"
+        geometry.GEOMETRIES[name] = dataclasses.replace(geometry.MINI, name=name, num_cam=num_views)
+        model = build_model(name, seed=0).eval()                          # CPU: the library's host path end to end
+        with torch.no_grad():
+            for i, layer in enumerate(model.world_feat.encoder.layers):
+                layer.self_attn.sampling_offsets.weight.normal_(0, 0.02, generator=torch.Generator().manual_seed(10 + i))
+                layer.self_attn.attention_weights.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(20 + i))
+        Hi, Wi = geometry.MINI.input_img_shape
+        imgs = torch.randn(1, num_views, 3, Hi, Wi, generator=torch.Generator().manual_seed(3))
+        M = geometry.random_affine_mats(1, num_views, (Hi, Wi), seed=2, translate=0.05, scale=(0.9, 1.1))
+        msgs = []
+        with torch.no_grad():
+            want = model(imgs, M)[0]
+            for encoder in ("sharded", "replicated"):
+                runner = mdist.ViewShardedFrame(model, encoder=encoder)
+                s, e = runner.range
+                assert (s, e) == mdist.partition_views(num_views, world)[rank]
+                got = runner(imgs[:, s:e], M)
+                err = max((got[0] - want[0]).abs().max().item(), (got[1] - want[1]).abs().max().item())
+                msgs.append(f"{encoder} {err:.2e}")
+                assert err < 5e-5, msgs
+        q.put((rank, True, "; ".join(msgs)))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_views", [7, 16])
+def test_view_sharded_frame_world8_both_encoder_modes(num_views):
+    """Whole frames (trunk, warp, token conv per view; then the query-sharded or the replicated shadow transformer) over 8
+    gloo ranks equal the single-process frame: 7 views -> rank 7 idles through every collective, 16 views -> 2 each."""
+    _run_world(_frame_worker, 8, (num_views,), timeout=600)
