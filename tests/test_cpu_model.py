@@ -73,3 +73,31 @@ def test_shared_reference_follows_the_reference_points_buffer():
     assert torch.equal(enc.shared_reference(), 0.5 * ref[..., 0, :].transpose(0, 1))
     enc.reference_points = torch.rand(12, 3, 4, 2)                         # replaced by a map with P distinct points
     assert enc.shared_reference() is None
+
+
+def test_config0_at_the_real_multiviewx_geometry_on_the_cpu():
+    """BASELINE.json configs[0] at its own size (only a 3-camera mini geometry had run): MultiviewX, 6 cameras,
+    3x720x1280 inputs, ResNet-18, --world_feat conv, CPU only.  The whole frame runs through the product (trunk: torch; warp:
+    the library's host path; ConvWorldFeat: torch), and the path's output -- warp + world features from the model's own
+    image features -- is checked against the oracle's kornia restatement + ConvWorldFeat restatement."""
+    geom = geometry.MULTIVIEWX
+    model = build_model("multiviewx", seed=0, world_feat_arch="conv", channels_last=False).eval()
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randn(1, geom.num_cam, 3, *geom.input_img_shape, generator=g)
+    M = geometry.random_affine_mats(1, geom.num_cam, geom.input_img_shape, seed=4, translate=0.05, scale=(0.9, 1.1))
+    assert imgs.shape == (1, 6, 3, 720, 1280) and model.Rworld_shape == (160, 250)
+    with torch.no_grad():
+        (wh, wo), (ih, io, iw) = model(imgs, M)
+        assert wh.shape == (1, 1, 160, 250) and wo.shape == (1, 2, 160, 250) and ih.shape == (6, 1, 90, 160)
+        feat = model.features(imgs)
+        proj = model.frame_proj_mats(M)
+        got = model.hot_path(feat, proj)
+        world = torch_oracle.warp_perspective(feat, proj, model.Rworld_shape).view(1, 6, -1, *model.Rworld_shape)
+        p = {k[len("world_feat."):]: v for k, v in model.state_dict().items() if k.startswith("world_feat.")}
+        want = torch_oracle.conv_world_feat(p, world)
+        # and the heads on top reproduce the frame's outputs
+        assert (model.world_heatmap(got) - wh).abs().max().item() < 1e-5
+    assert got.shape == want.shape == (1, 128, 160, 250)
+    scale = want.abs().max().item()
+    assert scale > 1e-3
+    assert (got - want).abs().max().item() < 1e-4 * max(1.0, scale)

@@ -156,3 +156,39 @@ def test_stress16_fused_entry_vs_unfused_and_oracle(ops):
     with torch.no_grad():
         want = torch_oracle.msda_module(params, query[:, sub], ref[:, sub], tokens, shapes, M, P)
     assert (got[:, sub] - want).abs().max().item() < FP32_TOL
+
+
+# ---- (d) configs[2]'s per-rank kernel at Wildtrack size ---------------------------------------------------
+@pytest.mark.parametrize("levels", [(0, 1), (6, 7), (0, 4), (4, 7)])
+def test_fused_query_levels_at_wildtrack_size_vs_oracle(ops, levels):
+    """mvdetr_msda_forward_fused_levels_f32 as ONE rank of a view-sharded Wildtrack frame calls it: value holds all 7
+    cameras' 75,600 tokens, the queries are the tokens of levels [l0, l1) -- 1-of-7 (first and last camera) and the 4 + 3
+    split of a 2-rank run.  Every query against the fp32 C oracle, a strided subset against fp64."""
+    MSDA, _, _ = ops
+    L, H, W, M, D, P = 7, 60, 180, 8, 16, 4
+    S = L * H * W
+    l0, l1 = levels
+    q0, q1 = l0 * H * W, l1 * H * W
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(L, H, W, M, D, P, seed=13)
+    # raw tensors whose module arithmetic reproduces (loc, aw) up to rounding: offsets in pixels around the identity
+    # reference grid, logits = log(weights)
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref1 = torch.stack([xs / W, ys / H], -1).reshape(-1, 2).repeat(L, 1)                            # [S, 2]
+    off = (loc - ref1[None, :, None, None, None, :]) * torch.tensor([W, H], dtype=torch.float32)    # [1, S, M, L, P, 2]
+    logit = aw.clamp_min(1e-30).log()
+    ref = ref1.view(1, S, 1, 1, 2).expand(1, S, L, P, 2).contiguous()
+    loc_k = torch_oracle.msda_sampling_locations(ref, off, shapes)
+    aw_k = torch.softmax(logit.flatten(3), -1).view(1, S, M, L, P)
+    dev = torch.device("cuda")
+    got = MSDA.ms_deform_attn_forward_fused(
+        value.to(dev), shapes.to(dev), lsi.to(dev), ref[:, q0:q1].contiguous().to(dev), off[:, q0:q1].contiguous().to(dev),
+        logit[:, q0:q1].contiguous().to(dev), query_levels=(l0, l1))
+    assert MSDA.last_forward_impl() == "tile_fused"
+    assert got.shape == (1, q1 - q0, M * D)
+    want = c_oracle.msda_forward(value, shapes, lsi, loc_k[:, q0:q1].contiguous(), aw_k[:, q0:q1].contiguous())
+    assert want.abs().max().item() > 0.5
+    assert (got.cpu() - want).abs().max().item() < FP32_TOL
+    sub = slice(0, q1 - q0, 97)
+    want64 = c_oracle.msda_forward(value.double(), shapes, lsi, loc_k[:, q0:q1][:, sub].double().contiguous(),
+                                   aw_k[:, q0:q1][:, sub].double().contiguous())
+    assert (got[:, sub].cpu().double() - want64).abs().max().item() < FP32_TOL
