@@ -423,10 +423,10 @@ __global__ __launch_bounds__(WARP_CL_THREADS) void warp_bwd_cl(
 //     grad_src is written once, with plain stores: it need not be zeroed, and each grad_dst row is read ~2.25 times
 //     (once per block its footprint touches), mostly from L2.  One difference from a scatter: a hit adds 0 * g to the
 //     block texels its footprint misses, so a NON-FINITE upstream gradient spreads to the other texels of the 2 x 2 block.
-//   * warp_bwd_stragglers: kornia divides by z only where |z| > 1e-8 (convert_points_from_homogeneous); a destination
-//     pixel with |z| <= 1e-8 samples a position unrelated to the projective map, so no scan finds it.  The gather skips
-//     such pixels and this kernel (one lane per destination pixel, returns at once unless |z| <= 1e-8) scatters them
-//     with atomics afterwards -- normally nothing.
+//   * Pixels kornia does not divide: convert_points_from_homogeneous divides by z only where |z| > 1e-8, so a destination
+//     pixel with |z| <= 1e-8 samples a position unrelated to the projective map and no scan finds it.  warp_bwd_scans
+//     lists such pixels (normally none) in pixel order; the gather tests the listed ones as extra candidates of every
+//     block and leaves them out of its scans, so they are counted exactly once and in a fixed order as well.
 template <typename T> struct WarpRec {
     int pix;                     // destination pixel index (n * H + i) * W + j
     int mask;                    // bit t: the footprint touches block texel t = 2 * (Y - 2by) + (X - 2bx)
@@ -454,6 +454,7 @@ template <typename T> __device__ __forceinline__ double source_pz(const T *__res
 constexpr int WARP_CLIP_MAXV = 12;      // rectangle (4) + one new vertex per clip (5), rounded up
 constexpr int WARP_CLIP_SLOTS = 4 * WARP_CLIP_MAXV + 15;        // polygon double buffer + the 5 x 3 coefficients
 constexpr int WARP_SCAN_THREADS = 64;
+constexpr int WARP_ODD_SEGS = 1024;     // workgroups (= list segments) that look for pixels kornia does not divide
 
 // bounding box of {(j, i) in [-1, W] x [-1, H] : e[k] . (j, i, 1) >= 0 for all k}; false when empty.  `lds` is this lane's
 // scratch, slot-major over the workgroup's lanes (slot s of lane l at lds[s * WARP_SCAN_THREADS]: conflict-free);
@@ -521,13 +522,51 @@ __device__ __forceinline__ WarpScan warp_scan_box(int i0, int i1, int j0, int j1
 template <typename T>
 __global__ __launch_bounds__(WARP_SCAN_THREADS) void warp_bwd_scans(const T *__restrict__ Mv, int N, int h, int w, int H,
                                                                     int W, int force_clip, int heavy_above,
-                                                                    WarpScan *__restrict__ scans, int *__restrict__ lists,
-                                                                    int *__restrict__ counts)
+                                                                    WarpScan *__restrict__ scans, int *__restrict__ heavy_list,
+                                                                    int *__restrict__ counts, int *__restrict__ odd_list)
 {
     __shared__ double clip[WARP_CLIP_SLOTS * WARP_SCAN_THREADS];
     const int bw2 = (w + 1) / 2, bh2 = (h + 1) / 2;
+    const int64_t nblk = (int64_t)N * bh2 * bw2;
+    const int scan_wgs = (int)((nblk + WARP_SCAN_THREADS - 1) / WARP_SCAN_THREADS);
+    if ((int)blockIdx.x >= scan_wgs) {
+        // The last WARP_ODD_SEGS workgroups: kornia divides by z only where |z| > 1e-8 (convert_points_from_homogeneous), so
+        // a destination pixel with |z| <= 1e-8 samples a position unrelated to the projective map and no scan finds it.
+        // Each of these workgroups (one wave) walks a contiguous range of destination pixels IN ORDER and lists the ones
+        // it finds (normally none) in its own segment: the gather then tests them as extra candidates, in a fixed order.
+        const int seg = (int)blockIdx.x - scan_wgs;
+        const int64_t npix = (int64_t)N * H * W, per = (npix + WARP_ODD_SEGS - 1) / WARP_ODD_SEGS;
+        const int64_t p0 = seg * per, p1 = min(npix, p0 + per);
+        const int lane = threadIdx.x;
+        int found = 0;
+        for (int64_t base = p0; base < p1; base += WARP_SCAN_THREADS) {
+            const int64_t p = base + lane;
+            bool odd = false;
+            if (p < p1) {
+                const int n = (int)(p / ((int64_t)H * W)), rem = (int)(p - (int64_t)n * H * W);
+                const int i = rem / W, j = rem - i * W;
+                // cheap screen first: z = zu / det with zu linear in (j, i); far from zero (a factor 4 of slack for the
+                // rounding of the exact expression) -> not odd, no division
+                const T *Mn = Mv + (int64_t)n * 9;
+                const double m0 = Mn[0], m1 = Mn[1], m2 = Mn[2], m3 = Mn[3], m4 = Mn[4], m5 = Mn[5], m6 = Mn[6], m7 = Mn[7],
+                             m8 = Mn[8];
+                const double det = m0 * (m4 * m8 - m5 * m7) + m1 * (m5 * m6 - m3 * m8) + m2 * (m3 * m7 - m4 * m6);
+                const double zu = (m3 * m7 - m4 * m6) * (double)j + (m1 * m6 - m0 * m7) * (double)i + (m0 * m4 - m1 * m3);
+                if (!(fabs(zu) > 4e-8 * fabs(det)))
+                    odd = fabs(source_pz(Mn, i, j)) <= 1e-8;                                // (NaN: neither scanned nor listed)
+            }
+            const uint64_t m = __ballot(odd);
+            if (odd) odd_list[p0 + found + __popcll(m & ((1ull << lane) - 1ull))] = (int)p;
+            found += __popcll(m);
+        }
+        if (lane == 0) {
+            counts[2 + seg] = found;
+            if (found) atomicAdd(counts + 1, found);
+        }
+        return;
+    }
     const int64_t idx = (int64_t)blockIdx.x * WARP_SCAN_THREADS + threadIdx.x;
-    if (idx >= (int64_t)N * bh2 * bw2) return;
+    if (idx >= nblk) return;
     const int n = (int)(idx / ((int64_t)bh2 * bw2)), rem = (int)(idx - (int64_t)n * bh2 * bw2);
     const int by = rem / bw2, bx = rem - by * bw2;
     const double xl = 2.0 * bx - 1.0, xh = 2.0 * bx + 2.0, yl = 2.0 * by - 1.0, yh = 2.0 * by + 2.0;
@@ -650,20 +689,24 @@ __global__ __launch_bounds__(WARP_SCAN_THREADS) void warp_bwd_scans(const T *__r
         if (c1.x <= c1.y) b1 = warp_scan_box(c1.x, c1.y, c1.z, c1.w);
     }
     }();
-    scans[2 * idx] = b0;
-    scans[2 * idx + 1] = b1;
-    // light blocks (incl. those without candidates: they still store zeros) and heavy ones go to separate work lists
+    // heavy blocks (far field: hundreds of candidates) go to a work list and are flagged in their first scan; the others are
+    // found by the gather's light waves directly
     const int64_t c0 = b0.u1 >= b0.u0 ? (int64_t)(b0.u1 - b0.u0 + 1) * b0.len : 0;
     const int64_t c1 = b1.u1 >= b1.u0 ? (int64_t)(b1.u1 - b1.u0 + 1) * b1.len : 0;
-    const int cls = c0 + c1 > heavy_above;
-    // one atomic per wave and list (25 K atomics on one address take 11 ns each: 285 us)
+    const bool is_heavy = c0 + c1 > heavy_above;
+    if (is_heavy) b0.swap |= 2;
+    scans[2 * idx] = b0;
+    scans[2 * idx + 1] = b1;
+    // one atomic per wave (25 K atomics on one address take 11 ns each: 285 us); the order inside the list does not matter
     const int lane = threadIdx.x & 63;
-    const uint64_t same = cls ? __ballot(cls == 1) : __ballot(cls == 0);
-    const int leader = __ffsll((unsigned long long)same) - 1;
-    int slot = 0;
-    if (lane == leader) slot = atomicAdd(counts + cls, __popcll(same));
-    slot = __shfl(slot, leader, 64) + __popcll(same & ((1ull << lane) - 1ull));
-    lists[(cls ? (int64_t)N * bh2 * bw2 : 0) + slot] = (int)idx;
+    const uint64_t hv = __ballot(is_heavy);
+    if (is_heavy) {
+        const int leader = __ffsll((unsigned long long)hv) - 1;
+        int slot = 0;
+        if (lane == leader) slot = atomicAdd(counts, __popcll(hv));
+        slot = __shfl(slot, leader, 64) + __popcll(hv & ((1ull << lane) - 1ull));
+        heavy_list[slot] = (int)idx;
+    }
 }
 #undef SLOT
 
@@ -673,32 +716,97 @@ constexpr int WARP_HEAVY_WGS = 2048;
 
 // The candidate rounds first, first + stride, ... (64 candidates each) of one 2 x 2 texel block, run by one wave.
 // Lane = (hit stream, channel chunk): with G = 2^lgG >= C/4 lanes per stream the wave runs 64 / G streams that take the
-// compacted hits round-robin (two at 128 channels).
+// compacted hits round-robin (two at 128 channels).  Candidates: the block's (up to two) scans, then -- normally none --
+// the listed pixels that kornia does not divide (counts[1] of them in all, counts[2 + seg] in segment seg of odd_list).
 template <typename T>
 __device__ __forceinline__ void warp_gather_rounds(
-    const T *__restrict__ gchunk, const T (&Mn)[9], const WarpScan *__restrict__ scans, int64_t blk, int n, int bx, int by,
-    int C, int h, int w, int H, int W, int nearest, int lgG, bool has_ch, int first, int stride, WarpRec<T> *mine,
-    T (&acc)[4][16 / (int)sizeof(T)])
+    const T *__restrict__ gchunk, const T (&Mn)[9], const WarpScan &sc0, const WarpScan &sc1, const int *__restrict__ counts,
+    const int *__restrict__ odd_list, int64_t odd_per, int n, int bx, int by, int C, int h, int w, int H, int W, int nearest,
+    int lgG, bool has_ch, int first, int stride, WarpRec<T> *mine, T (&acc)[4][16 / (int)sizeof(T)])
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     using Rec = WarpRec<T>;
     const int S = 64 >> lgG;
     const int lane = threadIdx.x & 63, st = lane >> lgG;
     const uint64_t below = (1ull << lane) - 1ull;
+
+    // one round: this lane's candidate (i, j) (if `cand`), an ordinary pixel (|z| > 1e-8) or a listed odd one
+    auto round = [&](bool cand, int i, int j, bool odd) {
+        bool hit = false;
+        Rec r;
+        r.pix = 0;
+        r.mask = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r.w[t] = T(0);
+        if (cand && (fabs(source_pz(Mn, i, j)) > 1e-8) != odd) {
+            double x, y;
+            source_position(Mn, i, j, h, w, x, y);
+            const SrcCoord c = make_coord(x, y, h, w, nearest);
+            const int dx = c.x0 - 2 * bx, dy = c.y0 - 2 * by;                      // corner 00 relative to the block
+            if (c.any && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) {
+                const T w00 = T(c.wy0 * c.wx0), w01 = T(c.wy0 * c.wx1);
+                const T w10 = T(c.wy1 * c.wx0), w11 = T(c.wy1 * c.wx1);
+                // corner (cy, cx) lies on block texel (dy + cy, dx + cx) when that is in {0, 1}^2
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ty = t >> 1, tx = t & 1, cy = ty - dy, cx = tx - dx;
+                    if (cy >= 0 && cy <= 1 && cx >= 0 && cx <= 1) {
+                        const bool ok = cy ? (cx ? c.v11 : c.v10) : (cx ? c.v01 : c.v00);
+                        const T ww = cy ? (cx ? w11 : w10) : (cx ? w01 : w00);
+                        if (ok) {
+                            r.mask |= 1 << t;
+                            r.w[t] = ww;
+                        }
+                    }
+                }
+                r.pix = ((n * H + i) * W + j) * C;                                  // element offset (< 2^31: checked on the host)
+                hit = r.mask != 0;
+            }
+        }
+        const uint64_t hits = __ballot(hit);
+        const int nhit = __popcll(hits);
+        if (hit) mine[__popcll(hits & below)] = r;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // stream st takes hits st, st + S, ...: WARP_GU of them in flight.  (q0 + u * S < nhit is wave-uniform: whole
+        // steps are skipped with a scalar branch; the one stream that runs out a hit early gets zero weights.)
+        for (int q0 = 0; q0 < nhit; q0 += WARP_GU * S) {
+            Pack<T, VEC> g[WARP_GU];
+#pragma unroll
+            for (int u = 0; u < WARP_GU; ++u) {               // the loads first (only the offsets are read here) ...
+                const int off = mine[min(q0 + u * S + st, nhit - 1)].pix;          // (clamped: branch-free, so they overlap)
+                g[u] = has_ch ? Pack<T, VEC>::load(gchunk + off) : Pack<T, VEC>::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < WARP_GU; ++u) {               // ... then the weights, re-read from LDS
+                if (q0 + u * S < nhit) {
+                    const int qq = q0 + u * S + st;
+                    const Rec rr = mine[min(qq, nhit - 1)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const T wt = qq < nhit ? rr.w[t] : T(0);           // (texels the footprint misses have weight 0)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[t][v] += wt * g[u].v[v];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
     for (int bsel = 0; bsel < 2; ++bsel) {
-        const WarpScan sc = scans[2 * blk + bsel];
+        const WarpScan &sc = bsel ? sc1 : sc0;
+        const int swap = sc.swap & 1;
         const int cnt = sc.u1 >= sc.u0 && sc.len > 0 ? (sc.u1 - sc.u0 + 1) * sc.len : 0;
-        const int V = sc.swap ? H : W;
+        const int V = swap ? H : W;
         const float rlen = 1.0f / (float)sc.len;
         const bool small = cnt < (1 << 22);                   // k * rlen is then within one of the quotient
         for (int base = first * 64; base < cnt; base += stride * 64) {
             const int k = base + lane;
-            bool hit = false;
-            Rec r;
-            r.pix = 0;
-            r.mask = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) r.w[t] = T(0);
+            int i = 0, j = 0;
+            bool cand = false;
             if (k < cnt) {
                 int du;
                 if (small) {
@@ -710,64 +818,31 @@ __device__ __forceinline__ void warp_gather_rounds(
                 }
                 const int u = sc.u0 + du;
                 const int v = (int)ceil(sc.a + sc.s * ((double)u - sc.uc)) + (k - du * sc.len);
-                const int i = sc.swap ? v : u, j = sc.swap ? u : v;
-                if (v >= 0 && v < V && fabs(source_pz(Mn, i, j)) > 1e-8) {
-                    double x, y;
-                    source_position(Mn, i, j, h, w, x, y);
-                    const SrcCoord c = make_coord(x, y, h, w, nearest);
-                    const int dx = c.x0 - 2 * bx, dy = c.y0 - 2 * by;              // corner 00 relative to the block
-                    if (c.any && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) {
-                        const T w00 = T(c.wy0 * c.wx0), w01 = T(c.wy0 * c.wx1);
-                        const T w10 = T(c.wy1 * c.wx0), w11 = T(c.wy1 * c.wx1);
-                        // corner (cy, cx) lies on block texel (dy + cy, dx + cx) when that is in {0, 1}^2
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int ty = t >> 1, tx = t & 1, cy = ty - dy, cx = tx - dx;
-                            if (cy >= 0 && cy <= 1 && cx >= 0 && cx <= 1) {
-                                const bool ok = cy ? (cx ? c.v11 : c.v10) : (cx ? c.v01 : c.v00);
-                                const T ww = cy ? (cx ? w11 : w10) : (cx ? w01 : w00);
-                                if (ok) {
-                                    r.mask |= 1 << t;
-                                    r.w[t] = ww;
-                                }
-                            }
-                        }
-                        r.pix = ((n * H + i) * W + j) * C;                          // element offset (< 2^31: checked on the host)
-                        hit = r.mask != 0;
-                    }
-                }
+                i = swap ? v : u;
+                j = swap ? u : v;
+                cand = v >= 0 && v < V;
             }
-            const uint64_t hits = __ballot(hit);
-            const int nhit = __popcll(hits);
-            if (hit) mine[__popcll(hits & below)] = r;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // stream st takes hits st, st + S, ...: WARP_GU of them in flight.  (q0 + u * S < nhit is wave-uniform: whole
-            // steps are skipped with a scalar branch; the one stream that runs out a hit early gets zero weights.)
-            for (int q0 = 0; q0 < nhit; q0 += WARP_GU * S) {
-                Pack<T, VEC> g[WARP_GU];
-#pragma unroll
-                for (int u = 0; u < WARP_GU; ++u) {           // the loads first (only the offsets are read here) ...
-                    const int off = mine[min(q0 + u * S + st, nhit - 1)].pix;      // (clamped: branch-free, so they overlap)
-                    g[u] = has_ch ? Pack<T, VEC>::load(gchunk + off) : Pack<T, VEC>::zero();
+            round(cand, i, j, false);
+        }
+    }
+    if (counts[1] != 0) {
+        // pixels kornia does not divide (listed by warp_bwd_scans, segment by segment in pixel order)
+        const int64_t npix = (int64_t)H * W;                  // per view
+        for (int seg = 0; seg < WARP_ODD_SEGS; ++seg) {
+            const int cnt = counts[2 + seg];
+            for (int base = first * 64; base < cnt; base += stride * 64) {
+                const int k = base + lane;
+                int i = 0, j = 0;
+                bool cand = false;
+                if (k < cnt) {
+                    const int p = odd_list[seg * odd_per + k];
+                    const int pn = (int)(p / npix), rem = (int)(p - pn * npix);
+                    i = rem / W;
+                    j = rem - i * W;
+                    cand = pn == n;
                 }
-#pragma unroll
-                for (int u = 0; u < WARP_GU; ++u) {           // ... then the weights, re-read from LDS
-                    if (q0 + u * S < nhit) {
-                        const int qq = q0 + u * S + st;
-                        const Rec rr = mine[min(qq, nhit - 1)];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const T wt = qq < nhit ? rr.w[t] : T(0);       // (texels the footprint misses have weight 0)
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[t][v] += wt * g[u].v[v];
-                        }
-                    }
-                }
+                round(cand, i, j, true);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
     }
     // the streams' partial sums, in a fixed order
@@ -778,15 +853,15 @@ __device__ __forceinline__ void warp_gather_rounds(
             for (int v = 0; v < VEC; ++v) acc[t][v] += __shfl_xor(acc[t][v], off, 64);
 }
 
-// Workgroups [0, WARP_HEAVY_WGS): the heavy blocks (far field: hundreds of candidates), one workgroup per (block, channel
-// group) at a time, its four waves taking the candidate rounds in turn and adding their partial sums in wave order.
-// The other workgroups: one WAVE per (light block, channel group).  lists = [light blocks | heavy blocks], counts = their
-// lengths (filled by warp_bwd_scans; the order inside a list does not matter).
+// Workgroups [0, WARP_HEAVY_WGS): the heavy blocks (far field: hundreds of candidates; listed by warp_bwd_scans), one
+// workgroup per (block, channel group) at a time, its four waves taking the candidate rounds in turn and adding their
+// partial sums in wave order.  The other workgroups: one WAVE per (block, channel group), which returns at once if the
+// block is flagged heavy.  counts = [heavy blocks, odd pixels, odd pixels per segment ...].
 template <typename T>
 __global__ __launch_bounds__(256) void warp_bwd_gather(
     const T *__restrict__ grad_dst, const T *__restrict__ Mv, const WarpScan *__restrict__ scans,
-    const int *__restrict__ lists, const int *__restrict__ counts, int N, int C, int h, int w, int H, int W, int nearest,
-    int lgG, int cgroups, T *__restrict__ grad_src)
+    const int *__restrict__ heavy_list, const int *__restrict__ counts, const int *__restrict__ odd_list, int N, int C, int h,
+    int w, int H, int W, int nearest, int lgG, int cgroups, T *__restrict__ grad_src)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ WarpRec<T> recs[4][64];
@@ -797,12 +872,13 @@ __global__ __launch_bounds__(256) void warp_bwd_gather(
     const int bw2 = (w + 1) / 2, bh2 = (h + 1) / 2;
     const int64_t nblk = (int64_t)N * bh2 * bw2;
     const bool heavy = blockIdx.x < WARP_HEAVY_WGS;
-    const int64_t nitems = (int64_t)(heavy ? counts[1] : counts[0]) * cgroups;
-    const int *const list = heavy ? lists + nblk : lists;
+    const int64_t nitems = heavy ? (int64_t)counts[0] * cgroups : nblk * cgroups;
     for (int64_t item = heavy ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x - WARP_HEAVY_WGS) * 4 + wv; item < nitems;
          item += heavy ? (int64_t)WARP_HEAVY_WGS : nitems) {
-        const int64_t blk = list[item / cgroups];
+        const int64_t blk = heavy ? (int64_t)heavy_list[item / cgroups] : item / cgroups;
         const int cgi = (int)(item % cgroups);
+        const WarpScan sc0 = scans[2 * blk], sc1 = scans[2 * blk + 1];
+        if (!heavy && (sc0.swap & 2)) return;                 // a heavy block: the workgroups above take it
         const int n = (int)(blk / ((int64_t)bh2 * bw2));
         const int rem = (int)(blk - (int64_t)n * bh2 * bw2);
         const int by = rem / bw2, bx = rem - by * bw2;
@@ -816,8 +892,9 @@ __global__ __launch_bounds__(256) void warp_bwd_gather(
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[t][v] = T(0);
-        warp_gather_rounds<T>(grad_dst + (int64_t)chunk * VEC, Mn, scans, blk, n, bx, by, C, h, w, H, W, nearest, lgG, has_ch,
-                              heavy ? wv : 0, heavy ? 4 : 1, recs[wv], acc);
+        const int64_t odd_per = ((int64_t)N * H * W + WARP_ODD_SEGS - 1) / WARP_ODD_SEGS;
+        warp_gather_rounds<T>(grad_dst + (int64_t)chunk * VEC, Mn, sc0, sc1, counts, odd_list, odd_per, n, bx, by, C, h, w, H,
+                              W, nearest, lgG, has_ch, heavy ? wv : 0, heavy ? 4 : 1, recs[wv], acc);
         if (heavy) {
             if (wv > 0 && st == 0)
 #pragma unroll
@@ -848,32 +925,6 @@ __global__ __launch_bounds__(256) void warp_bwd_gather(
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void warp_bwd_stragglers(
-    const T *__restrict__ grad_dst, const T *__restrict__ Mv, int N, int C, int h, int w, int H, int W, int nearest,
-    T *__restrict__ grad_src)
-{
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= (int64_t)N * H * W) return;
-    const int n = (int)(p / ((int64_t)H * W)), rem = (int)(p - (int64_t)n * H * W), i = rem / W, j = rem - i * W;
-    const T *Mn = Mv + (int64_t)n * 9;
-    if (fabs(source_pz(Mn, i, j)) > 1e-8) return;                  // NaN: the forward stores zeros there, no gradient
-    double x, y;
-    source_position(Mn, i, j, h, w, x, y);
-    const SrcCoord sc = make_coord(x, y, h, w, nearest);
-    if (!sc.any) return;
-    const T w00 = T(sc.wy0 * sc.wx0), w01 = T(sc.wy0 * sc.wx1), w10 = T(sc.wy1 * sc.wx0), w11 = T(sc.wy1 * sc.wx1);
-    T *gp = grad_src + (((int64_t)n * h + sc.y0) * w + sc.x0) * C;
-    const T *g = grad_dst + p * C;
-    const int64_t rowC = (int64_t)w * C;
-    for (int c = 0; c < C; ++c) {
-        if (sc.v00) atomicAdd(gp + c, w00 * g[c]);
-        if (sc.v01) atomicAdd(gp + C + c, w01 * g[c]);
-        if (sc.v10) atomicAdd(gp + rowC + c, w10 * g[c]);
-        if (sc.v11) atomicAdd(gp + rowC + C + c, w11 * g[c]);
-    }
-}
-
 // Which kernel the last warp call of this process launched (tests assert the layout routes; bench.py reports it).  Not
 // thread-local: autograd runs the backward on its own thread.
 static std::atomic<const char *> g_warp_last_kernel{"none"};
@@ -901,22 +952,31 @@ static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv
     if (wgs > 0x7fffffffLL || npix * C > 0x7fffffffLL) return (int)hipErrorNotSupported;
     const char *ge = getenv("MVDETR_WARP_BWD_GEOMETRY");
     const int force_clip = ge && !strcmp(ge, "clip");
-    // stream-ordered scratch: [scans: 2 per block | work lists: light, heavy | their two lengths]
-    const size_t scan_bytes = (size_t)nblk * 2 * sizeof(WarpScan), list_bytes = (size_t)nblk * 2 * sizeof(int);
+    // stream-ordered scratch: [counts: heavy, odd, odd per segment | scans: 2 per block | heavy-block list | odd-pixel list]
+    const size_t count_bytes = ((2 + WARP_ODD_SEGS) * sizeof(int) + 15) / 16 * 16;
+    const size_t scan_bytes = (size_t)nblk * 2 * sizeof(WarpScan), heavy_bytes = (size_t)nblk * sizeof(int);
+    const int64_t odd_per = (npix + WARP_ODD_SEGS - 1) / WARP_ODD_SEGS;
+    const size_t odd_bytes = (size_t)odd_per * WARP_ODD_SEGS * sizeof(int);
     char *scratch = nullptr;
-    hipError_t rc = hipMallocAsync(reinterpret_cast<void **>(&scratch), scan_bytes + list_bytes + 2 * sizeof(int), st);
+    hipError_t rc = hipMallocAsync(reinterpret_cast<void **>(&scratch), count_bytes + scan_bytes + heavy_bytes + odd_bytes, st);
     if (rc != hipSuccess) return (int)rc;
-    WarpScan *scans = reinterpret_cast<WarpScan *>(scratch);
-    int *lists = reinterpret_cast<int *>(scratch + scan_bytes), *counts = lists + 2 * nblk;
-    rc = hipMemsetAsync(counts, 0, 2 * sizeof(int), st);
+    int *counts = reinterpret_cast<int *>(scratch);
+    WarpScan *scans = reinterpret_cast<WarpScan *>(scratch + count_bytes);
+    int *heavy_list = reinterpret_cast<int *>(scratch + count_bytes + scan_bytes);
+    int *odd_list = reinterpret_cast<int *>(scratch + count_bytes + scan_bytes + heavy_bytes);
+    // the two running counters start from zero: one 8-byte stream write (a command-processor packet, no fill kernel)
+    rc = hipStreamWriteValue64(st, counts, 0, 0);
+    if (rc != hipSuccess) {
+        (void)hipGetLastError();
+        rc = hipMemsetAsync(counts, 0, 2 * sizeof(int), st);
+    }
     const char *he = getenv("MVDETR_WARP_BWD_HEAVY");        // (test knob: 0 = every block with candidates is "heavy")
     const int heavy_above = he ? atoi(he) : WARP_HEAVY;
-    hipLaunchKernelGGL((warp_bwd_scans<T>), dim3((unsigned)((nblk + WARP_SCAN_THREADS - 1) / WARP_SCAN_THREADS)),
-                       dim3(WARP_SCAN_THREADS), 0, st, Mv, N, h, w, H, W, force_clip, heavy_above, scans, lists, counts);
+    const int64_t scan_wgs = (nblk + WARP_SCAN_THREADS - 1) / WARP_SCAN_THREADS;
+    hipLaunchKernelGGL((warp_bwd_scans<T>), dim3((unsigned)(scan_wgs + WARP_ODD_SEGS)), dim3(WARP_SCAN_THREADS), 0, st, Mv, N,
+                       h, w, H, W, force_clip, heavy_above, scans, heavy_list, counts, odd_list);
     hipLaunchKernelGGL((warp_bwd_gather<T>), dim3((unsigned)(wgs + WARP_HEAVY_WGS)), dim3(256), 0, st, grad_dst, Mv, scans,
-                       lists, counts, N, C, h, w, H, W, nearest, lgG, cgroups, grad_src);
-    hipLaunchKernelGGL((warp_bwd_stragglers<T>), dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, grad_dst, Mv, N, C,
-                       h, w, H, W, nearest, grad_src);
+                       heavy_list, counts, odd_list, N, C, h, w, H, W, nearest, lgG, cgroups, grad_src);
     if (rc == hipSuccess) rc = hipGetLastError();
     (void)hipFreeAsync(scratch, st);
     return (int)rc;

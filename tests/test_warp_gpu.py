@@ -377,7 +377,8 @@ def test_backward_gather_horizon_inside_the_view(warp, dtype, geometry_env, near
 
 def test_backward_gather_pixels_kornia_does_not_divide(warp):
     """|z| <= 1e-8: kornia's convert_points_from_homogeneous leaves the point undivided, so that destination column samples a
-    position unrelated to the projective map.  The gather skips those pixels, warp_bwd_stragglers adds them."""
+    position unrelated to the projective map.  The gather's scans skip those pixels; warp_bwd_scans lists them and the
+    gather takes the listed ones as extra candidates."""
     A = torch.tensor([[1.0, 0, 0], [0, 1, 0], [1, 0, -4]], dtype=torch.float64)        # M^-1: z = j - 4
     M = torch.linalg.inv(A)[None]
     n, c, h, w, H, W = 1, 4, 12, 16, 10, 9
@@ -393,7 +394,10 @@ def test_backward_gather_pixels_kornia_does_not_divide(warp):
     assert (gs.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 1e-12
     only_col = torch.zeros_like(go)
     only_col[:, :, 4] = go[:, :, 4]
-    assert _bwd_cl(only_col.cuda(), M, n, c, h, w).abs().max().item() > 0.1            # the stragglers carry gradient
+    assert _bwd_cl(only_col.cuda(), M, n, c, h, w).abs().max().item() > 0.1            # the listed pixels carry gradient
+    assert torch.equal(_bwd_cl(go.cuda(), M, n, c, h, w), gs)                          # ... deterministically
+    gh = _bwd_cl(go.cuda(), M, n, c, h, w, env={"MVDETR_WARP_BWD_HEAVY": "0"})         # and through the workgroup path
+    assert (gh.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 1e-12
 
 
 @pytest.mark.parametrize("C,dtype", [(4, torch.float32), (8, torch.float64), (36, torch.float32), (256, torch.float32),
