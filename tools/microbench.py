@@ -126,7 +126,15 @@ def bench_warp(a, geom, L, C):
             out = warp_perspective(leaf, Mx, (Hw, Ww), channels_last_out=nhwc)
             go = torch.randn_like(out)
             fn = lambda: torch.autograd.grad(out, leaf, go, retain_graph=True)  # noqa: E731
-            report(f"warp_bwd {tag} (+memset)", time_us(fn, max(5, a.iters // 3)), wbytes)
+            report(f"warp_bwd {tag} (autograd)", time_us(fn, max(5, a.iters // 3)), wbytes)
+    if not a.skip_bwd:
+        # the channel-last backward at the C ABI (no autograd / Python in the timed region)
+        from mvdetr_amd.ops import warp as warp_mod
+        go = torch.randn(L, Hw, Ww, C, device="cuda")
+        gs = torch.empty(L, h, w, C, device="cuda")
+        Mc = Mx.reshape(-1, 3, 3).float().contiguous()
+        report("warp_bwd NHWC, C ABI entry", time_us(lambda: warp_mod._launch("backward", go, Mc, L, C, h, w, Hw, Ww, 3, gs),
+                                                        max(10, a.iters)), wbytes)
     # for scale: a plain device copy of the same number of bytes
     x = torch.empty(wbytes // 8, device="cuda")
     y = torch.empty_like(x)

@@ -3,9 +3,12 @@
 # (forward / backward / warp) and their kernel trace.  Everything lands in gpurun_out/profile_<tag>/.
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/profile_$TAG; mkdir -p $O; cd $R
+# the PMC passes first, so that the bench line below quotes THIS round's memory-side traffic (bench.py reads the newest
+# profiles/*_traffic.json; the copy into profiles/ here is in the box's scratch checkout -- commit it from gpurun_out/)
+bash tools/profile_bench.sh $TAG > $O/profile_bench.log 2>&1
+cp $O/${TAG}_traffic.json $R/profiles/ 2>/dev/null
 python bench.py 2> $O/bench_stderr.log | tail -1 > $O/${TAG}_bench.json
 cat $O/${TAG}_bench.json
-bash tools/profile_bench.sh $TAG > $O/profile_bench.log 2>&1
 (python tools/microbench.py --iters 30; python tools/microbench.py --iters 10 --config multiviewx; python tools/microbench.py --iters 5 --config stress16) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_microbench.txt
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace -d $O/mb_trace -o t -- python $R/tools/microbench.py --iters 10 > /dev/null 2>&1
