@@ -163,8 +163,9 @@ int mvdetr_warp_perspective_forward_f64(void *stream, const double *src, const d
  *            OVERWRITTEN: every element is stored, it need not be zeroed (ABI 9; up to ABI 8 it had to be zero on entry)
  * With both sides channel-last (layout_nhwc & 3 == 3) the gradient is computed as a GATHER over the destination pixels
  * whose bilinear footprint touches each source texel (the homography is invertible): no atomics, the order of every
- * sum is fixed, so the result is deterministic -- unlike grid_sample's atomicAdd backward.  It allocates
- * 32 bytes per 2x2 block of source texels of stream-ordered scratch (hipMallocAsync / hipFreeAsync on `stream`).
+ * sum is fixed, so the result is deterministic -- unlike grid_sample's atomicAdd backward.  It uses
+ * stream-ordered scratch (80 bytes per 2x2 block of source texels + 4 bytes per destination pixel, hipMallocAsync on
+ * `stream`), kept per (device, stream) between calls and grown on demand.
  * The other layouts scatter with fp atomics after a hipMemsetAsync (MVDETR_WARP_BWD_IMPL=scatter forces that for
  * channel-last tensors too).
  */

@@ -18,6 +18,9 @@
 #include "common.h"
 #include "../../include/mvdetr_ops.h"
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstdlib>
 #include <cstring>
 
@@ -853,7 +856,7 @@ __device__ __forceinline__ void warp_gather_rounds(
             for (int v = 0; v < VEC; ++v) acc[t][v] += __shfl_xor(acc[t][v], off, 64);
 }
 
-// Workgroups [0, WARP_HEAVY_WGS): the heavy blocks (far field: hundreds of candidates; listed by warp_bwd_scans), one
+// Workgroups [0, heavy_wgs): the heavy blocks (far field: hundreds of candidates; listed by warp_bwd_scans), one
 // workgroup per (block, channel group) at a time, its four waves taking the candidate rounds in turn and adding their
 // partial sums in wave order.  The other workgroups: one WAVE per (block, channel group), which returns at once if the
 // block is flagged heavy.  counts = [heavy blocks, odd pixels, odd pixels per segment ...].
@@ -861,7 +864,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void warp_bwd_gather(
     const T *__restrict__ grad_dst, const T *__restrict__ Mv, const WarpScan *__restrict__ scans,
     const int *__restrict__ heavy_list, const int *__restrict__ counts, const int *__restrict__ odd_list, int N, int C, int h,
-    int w, int H, int W, int nearest, int lgG, int cgroups, T *__restrict__ grad_src)
+    int w, int H, int W, int nearest, int lgG, int cgroups, int heavy_wgs, T *__restrict__ grad_src)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
     __shared__ WarpRec<T> recs[4][64];
@@ -871,10 +874,10 @@ __global__ __launch_bounds__(256) void warp_bwd_gather(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: block, view, matrix and scans live in SGPRs)
     const int bw2 = (w + 1) / 2, bh2 = (h + 1) / 2;
     const int64_t nblk = (int64_t)N * bh2 * bw2;
-    const bool heavy = blockIdx.x < WARP_HEAVY_WGS;
+    const bool heavy = (int)blockIdx.x < heavy_wgs;
     const int64_t nitems = heavy ? (int64_t)counts[0] * cgroups : nblk * cgroups;
-    for (int64_t item = heavy ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x - WARP_HEAVY_WGS) * 4 + wv; item < nitems;
-         item += heavy ? (int64_t)WARP_HEAVY_WGS : nitems) {
+    for (int64_t item = heavy ? (int64_t)blockIdx.x : ((int64_t)blockIdx.x - heavy_wgs) * 4 + wv; item < nitems;
+         item += heavy ? (int64_t)heavy_wgs : nitems) {
         const int64_t blk = heavy ? (int64_t)heavy_list[item / cgroups] : item / cgroups;
         const int cgi = (int)(item % cgroups);
         const WarpScan sc0 = scans[2 * blk], sc1 = scans[2 * blk + 1];
@@ -937,6 +940,29 @@ static int warp_bwd_impl()
     return e && !strcmp(e, "scatter") ? 1 : 0;
 }
 
+// Scratch of the gather backward, one buffer per (device, stream), grown on demand and kept for the life of the process: every
+// use is enqueued on that stream, so reuse is ordered; calls on different streams get different buffers (thread-safe).
+static char *warp_stream_scratch(hipStream_t st, size_t bytes, hipError_t &rc)
+{
+    struct Entry { char *ptr; size_t size; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Entry> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    Entry &e = cache[{dev, st}];
+    if (e.size < bytes) {
+        if (e.ptr) (void)hipFreeAsync(e.ptr, st);              // (after the work already queued on this stream)
+        e.ptr = nullptr;
+        e.size = 0;
+        const size_t want = bytes + bytes / 4;
+        rc = hipMallocAsync(reinterpret_cast<void **>(&e.ptr), want, st);
+        if (rc != hipSuccess) { e.ptr = nullptr; return nullptr; }
+        e.size = want;
+    }
+    return e.ptr;
+}
+
 template <typename T>
 static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv, int N, int C, int h, int w, int H,
                                   int W, int nearest, T *grad_src)
@@ -957,9 +983,10 @@ static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv
     const size_t scan_bytes = (size_t)nblk * 2 * sizeof(WarpScan), heavy_bytes = (size_t)nblk * sizeof(int);
     const int64_t odd_per = (npix + WARP_ODD_SEGS - 1) / WARP_ODD_SEGS;
     const size_t odd_bytes = (size_t)odd_per * WARP_ODD_SEGS * sizeof(int);
-    char *scratch = nullptr;
-    hipError_t rc = hipMallocAsync(reinterpret_cast<void **>(&scratch), count_bytes + scan_bytes + heavy_bytes + odd_bytes, st);
-    if (rc != hipSuccess) return (int)rc;
+    // (kept per stream between calls: hipMallocAsync + hipFreeAsync cost the host ~10 us per call, more than the launches)
+    hipError_t rc = hipSuccess;
+    char *scratch = warp_stream_scratch(st, count_bytes + scan_bytes + heavy_bytes + odd_bytes, rc);
+    if (!scratch) return (int)rc;
     int *counts = reinterpret_cast<int *>(scratch);
     WarpScan *scans = reinterpret_cast<WarpScan *>(scratch + count_bytes);
     int *heavy_list = reinterpret_cast<int *>(scratch + count_bytes + scan_bytes);
@@ -975,10 +1002,11 @@ static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv
     const int64_t scan_wgs = (nblk + WARP_SCAN_THREADS - 1) / WARP_SCAN_THREADS;
     hipLaunchKernelGGL((warp_bwd_scans<T>), dim3((unsigned)(scan_wgs + WARP_ODD_SEGS)), dim3(WARP_SCAN_THREADS), 0, st, Mv, N,
                        h, w, H, W, force_clip, heavy_above, scans, heavy_list, counts, odd_list);
-    hipLaunchKernelGGL((warp_bwd_gather<T>), dim3((unsigned)(wgs + WARP_HEAVY_WGS)), dim3(256), 0, st, grad_dst, Mv, scans,
-                       heavy_list, counts, odd_list, N, C, h, w, H, W, nearest, lgG, cgroups, grad_src);
+    const char *hw = getenv("MVDETR_WARP_BWD_HEAVY_WGS");
+    const int heavy_wgs = hw ? (atoi(hw) > 0 ? atoi(hw) : 1) : WARP_HEAVY_WGS;
+    hipLaunchKernelGGL((warp_bwd_gather<T>), dim3((unsigned)(wgs + heavy_wgs)), dim3(256), 0, st, grad_dst, Mv, scans,
+                       heavy_list, counts, odd_list, N, C, h, w, H, W, nearest, lgG, cgroups, heavy_wgs, grad_src);
     if (rc == hipSuccess) rc = hipGetLastError();
-    (void)hipFreeAsync(scratch, st);
     return (int)rc;
 }
 
