@@ -380,6 +380,165 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
     }
 }
 
+// ---- level GROUPS resident: D = 32, or more than 7 levels (the 16-camera rig: D = 32, L = 16) ----------------------------
+// msda_bwd_sampling_resident keeps ALL L windows of a head in LDS, which stops at 7 levels of 16-channel heads (143 KB); the
+// tile kernel that took over beyond that stages every window once per QUERY level (5.0 ms at the stress configuration).
+// Same job here -- (4 x 8 cells, one head), lane = (camera, cell, half head) -- but the source levels pass through LDS in
+// groups of LG (3 windows of 16 x 20 tokens x 128 B at D = 32), and the cameras in passes of 8 (one wave per camera), so
+// every window is still staged once per (tile, head).  A lane's sampling data / gradients of a level group are contiguous
+// runs of LG x 32 / LG x 16 bytes.
+template <int D, int LG>
+__global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_groups(
+    const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
+    const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
+    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw, const int *__restrict__ local_hits)
+{
+    extern __shared__ __attribute__((aligned(16))) float vwin[];      // [LG][RS_NTOK][D]
+    constexpr int TH = RS_TH, TW = RS_TW, WH = RS_WH, WW = RS_WW, NTOK = RS_NTOK, P = TILE_P;
+    constexpr int HALF = D / 2, NV = HALF / 4, CH = D / 4, POS = 64 / CH, CAMS = RS_THREADS / 64;
+    static_assert(NTOK % POS == 0, "a DMA instruction covers POS window positions");
+    const int tid = threadIdx.x;
+    const int64_t row = (int64_t)M * D;
+
+    bool equal = true;
+    for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
+    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
+    if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
+
+    const int Hq = (int)shapes[0], Wq = (int)shapes[1];
+    const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
+    const int jobs = per_level * M * B, jobs8 = (jobs + 7) / 8;
+    const float fW = (float)Wq, fH = (float)Hq;
+
+    // lane = (camera of the pass, cell, half of the head's channels): a wave is one camera's 32 cells
+    const int sub = tid & 1, qi = (tid >> 1) & (TH * TW - 1), qly = qi / TW, qlx = qi % TW;
+    const int rot = (qlx / (64 / D)) & (NV - 1);              // LDS bank spreading, as in msda_tile_body.h
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int my_pos = lane / CH, my_chunk = lane % CH;       // window copy: POS positions x CH 16-byte chunks per instruction
+
+    for (int t = blockIdx.x; t < jobs8 * 8; t += gridDim.x) {
+        const int job = (t & 7) * jobs8 + (t >> 3);          // XCD k takes a contiguous band of jobs
+        if ((t >> 3) >= jobs8 || job >= jobs) continue;
+        const int head = job % M, u2 = job / M;               // the heads of a tile run back to back: same token rows
+        const int tin = u2 % per_level, b = u2 / per_level;
+        const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
+        const int qy = Y0 + qly, qx = X0 + qlx;
+        const bool in_level = qy < Hq && qx < Wq;
+        const float *vbatch = value + (int64_t)b * S * row + head * D;
+        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+        const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
+
+        for (int g0 = 0; g0 < L; g0 += LG) {
+            const int ng = min(LG, L - g0);
+            __syncthreads();                                  // everyone is done reading the previous group's windows
+            {
+                const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(vbatch), 0, (int)((unsigned)S * (unsigned)row * 4u - (unsigned)(head * D) * 4u), 0x00020000);
+                for (int k = wave_u; k < NTOK / POS; k += RS_THREADS / 64) {
+                    const int wp = k * POS + my_pos, wy = wp / WW, wx = wp % WW, gy = oy + wy, gx = ox + wx;
+                    const unsigned vo = ((unsigned)gx < (unsigned)Wq && (unsigned)gy < (unsigned)Hq)
+                                            ? (unsigned)((gy * Wq + gx) * (int)row + my_chunk * 4) * 4u : 0x80000000u;
+                    for (int j = 0; j < ng; ++j) {
+                        const unsigned so = (unsigned)((int)lsi[g0 + j] * (int)row) * 4u;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(vwin + (j * NTOK + k * POS) * D),
+                                                                 16, (int)vo, (int)so, 0, 0);
+                    }
+                }
+            }
+            for (int c0 = 0; c0 < L; c0 += CAMS) {
+                const int cam = c0 + wave_u;                  // wave-uniform
+                const bool active = in_level && cam < L;
+                const int64_t q = (int64_t)b * S + lsi[cam < L ? cam : L - 1] + (active ? (int64_t)qy * Wq + qx : 0);
+                const int64_t e0 = ((q * M + head) * L + g0) * P;     // this (query, head)'s first tap of the group
+                float4 g[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const float4 *>(go + q * row + head * D + sub * HALF + ((k ^ rot) << 2));
+                float4 la[LG], lb[LG], wa[LG];
+#pragma unroll
+                for (int j = 0; j < LG; ++j) {
+                    const int jj = j < ng ? j : ng - 1;
+                    la[j] = *reinterpret_cast<const float4 *>(loc + (e0 + jj * P) * 2);
+                    lb[j] = *reinterpret_cast<const float4 *>(loc + (e0 + jj * P) * 2 + 4);
+                    wa[j] = *reinterpret_cast<const float4 *>(aw + e0 + jj * P);
+                }
+                if (c0 == 0) __syncthreads();                 // the group's windows have landed
+                float4 r_aw[LG], r_l0[LG], r_l1[LG];
+#pragma unroll
+                for (int j = 0; j < LG; ++j) {
+                    if (j >= ng) continue;                    // (uniform)
+                    const float *wl = vwin + j * NTOK * D;
+                    const float xs[4] = {la[j].x * fW - 0.5f, la[j].z * fW - 0.5f, lb[j].x * fW - 0.5f, lb[j].z * fW - 0.5f};
+                    const float ys[4] = {la[j].y * fH - 0.5f, la[j].w * fH - 0.5f, lb[j].y * fH - 0.5f, lb[j].w * fH - 0.5f};
+                    const float as[4] = {wa[j].x, wa[j].y, wa[j].z, wa[j].w};
+                    float ga[4], gx[4], gy[4];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float x = xs[p], y = ys[p];
+                        f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
+                        if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
+                            const int ix = (int)floorf(x) - ox, iy = (int)floorf(y) - oy;
+                            const float *p00 = wl + (iy * WW + ix) * D + sub * HALF;
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) {
+                                const float *pk = p00 + ((k ^ rot) << 2);
+                                q00 = dot4(g[k], *reinterpret_cast<const float4 *>(pk), q00);
+                                q01 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + D), q01);
+                                q10 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D), q10);
+                                q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D + D), q11);
+                            }
+                        } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {   // (lanes without a cell carry cell 0's taps)
+                            corners_from_memory<NV>(vbatch + lsi[g0 + j] * row + sub * HALF, row, Hq, Wq, x, y, rot, g, q00, q01, q10, q11);
+                        }
+                        float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+                        d00 += neighbour(d00);                // the other half of the head sits in the neighbouring lane
+                        d01 += neighbour(d01);
+                        d10 += neighbour(d10);
+                        d11 += neighbour(d11);
+                        const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                        const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
+                        ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
+                        gx[p] = in_image ? fW * as[p] * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+                        gy[p] = in_image ? fH * as[p] * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                        __builtin_amdgcn_sched_barrier(0);    // one tap's LDS reads in flight at a time
+                    }
+                    r_aw[j] = make_float4(ga[0], ga[1], ga[2], ga[3]);
+                    r_l0[j] = make_float4(gx[0], gy[0], gx[1], gy[1]);
+                    r_l1[j] = make_float4(gx[2], gy[2], gx[3], gy[3]);
+                }
+                if (active && sub == 0) {
+#pragma unroll
+                    for (int j = 0; j < LG; ++j) {
+                        if (j >= ng) continue;
+                        *reinterpret_cast<float4 *>(grad_aw + e0 + j * P) = r_aw[j];
+                        *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2) = r_l0[j];
+                        *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2 + 4) = r_l1[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int D, int LG>
+static int launch_sampling_groups(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                  const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
+                                  float *grad_loc, float *grad_aw, const int *local_hits)
+{
+    constexpr int LDS = LG * RS_NTOK * D * 4;
+    static int blocks = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_groups<D, LG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 256;
+        return (cus + 7) / 8 * 8;                             // one workgroup per CU (LDS)
+    }();
+    hipLaunchKernelGGL((msda_bwd_sampling_groups<D, LG>), dim3((unsigned)blocks), dim3(RS_THREADS), LDS, st, go, value, shapes,
+                       lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits);
+    return (int)hipGetLastError();
+}
+
 static int launch_sampling_resident(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                     const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
                                     float *grad_loc, float *grad_aw, const int *local_hits)
@@ -431,6 +590,10 @@ int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *va
 #define SAMPLING_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits
     static const bool resident_ok = [] { const char *e = getenv("MVDETR_MSDA_BWD_SAMPLING"); return !(e && !strcmp(e, "tile")); }();
     if (resident_ok && D == RS_D && L <= RS_MAXL && (int64_t)S * M * D * 4 < 0x7fffffffLL) return launch_sampling_resident(SAMPLING_ARGS);
+    // more levels or 32-channel heads: the same job with the levels passing through LDS in groups
+    // (MVDETR_MSDA_BWD_SAMPLING=tile keeps the per-query-level tile kernel)
+    if (resident_ok && D == 32) return launch_sampling_groups<32, 3>(SAMPLING_ARGS);
+    if (resident_ok && D == 16) return launch_sampling_groups<16, 7>(SAMPLING_ARGS);
     if (D == 16) return L <= 8 ? launch_sampling_tile<SWide16, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide16, 16>(SAMPLING_ARGS);
     if (D == 32) return L <= 8 ? launch_sampling_tile<SWide32, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide32, 16>(SAMPLING_ARGS);
     return (int)hipErrorInvalidValue;
