@@ -386,9 +386,10 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
 // Same job here -- (4 x 8 cells, one head), lane = (camera, cell, half head) -- but the source levels pass through LDS in
 // groups of LG (3 windows of 16 x 20 tokens x 128 B at D = 32), and the cameras in passes of 8 (one wave per camera), so
 // every window is still staged once per (tile, head).  A lane's sampling data / gradients of a level group are contiguous
-// runs of LG x 32 / LG x 16 bytes.
-template <int D, int LG>
-__global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_groups(
+// runs of LG x 32 / LG x 16 bytes.  (At Wildtrack size -- D = 16, L = 7 -- groups of 3 are no faster than all 7 resident:
+// 764 vs 747 us for the whole backward with one workgroup per CU, 827 us with two at 128 VGPRs, which spill.)
+template <int D, int LG, int WPE = 2>
+__global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
     int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw, const int *__restrict__ local_hits)
@@ -519,22 +520,22 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_groups(
     }
 }
 
-template <int D, int LG>
+template <int D, int LG, int WPE = 2>
 static int launch_sampling_groups(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                   const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
                                   float *grad_loc, float *grad_aw, const int *local_hits)
 {
     constexpr int LDS = LG * RS_NTOK * D * 4;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_groups<D, LG>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_groups<D, LG, WPE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        return (cus + 7) / 8 * 8;                             // one workgroup per CU (LDS)
+        return (cus * (WPE / 2) + 7) / 8 * 8;                 // WPE / 2 workgroups of 8 waves per CU
     }();
-    hipLaunchKernelGGL((msda_bwd_sampling_groups<D, LG>), dim3((unsigned)blocks), dim3(RS_THREADS), LDS, st, go, value, shapes,
+    hipLaunchKernelGGL((msda_bwd_sampling_groups<D, LG, WPE>), dim3((unsigned)blocks), dim3(RS_THREADS), LDS, st, go, value, shapes,
                        lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits);
     return (int)hipGetLastError();
 }
