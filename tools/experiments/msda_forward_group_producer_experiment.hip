@@ -8,8 +8,11 @@
 // producer's global loads removed (garbage data, timing only) the same protocol runs at 115.6 us (init weights), i.e. the
 // hand-over itself is free and ~5 us below the baseline; what costs 3.4 us per step is the single wave's 11 scattered
 // 64-lane loads per step (about 275 cache lines), whose completion the compiler's s_waitcnt vmcnt(0) at every hand-over
-// waits for.  Not understood further; a DMA (buffer_load ... lds) producer or loads spread over the compute waves' idle
-// issue slots would be the next things to try.
+// waits for: LDS-only fences ("workgroup", "local") change nothing, and fully unrolling the 49 steps does not give
+// counted waits either (the spin loops keep hipcc's waitcnt insertion at vmcnt(0): 93 of them in the ISA), so whatever
+// the look-ahead, every hand-over waits for the loads issued one step earlier.  A producer written with counted
+// s_waitcnt vmcnt(N) (inline asm, which DESIGN.md 4.1c lists as unsafe with hipcc) or a DMA (buffer_load ... lds)
+// producer would be the next things to try.
 // Multi-scale deformable attention forward, fused + camera-grouped LDS-tiled kernel -- gfx950 (MI355X).
 //
 // What bounds msda_fwd_tile is the window staging: every (tile, slice, QUERY level) workgroup copies the
@@ -167,13 +170,13 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                 auto hand_over = [&](float4 (&pr)[11], int st_) {
                     while (__hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < COMPUTE_WAVES * st_)
                         __builtin_amdgcn_s_sleep(1);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 #pragma unroll
                     for (int j = 0; j < 11; ++j) {
                         const int item = lane + j * 64, pc = item / 7, piece = item - pc * 7;
                         if (pc < TH * TW) *reinterpret_cast<float4 *>(samp + pc * GP_SLOT_FLOATS + piece * 4) = pr[j];
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
                     if (lane == 0) __hip_atomic_store(flags, st_ + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     prod_load(pr, st_ + GP_DEPTH);
                 };
@@ -204,7 +207,10 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     __syncthreads();
                 };
                 // steps in groups of GP_DEPTH so that the register set of a step (its index modulo GP_DEPTH) is static
-                for (int s0 = 0; s0 < L * NG; s0 += GP_DEPTH) {
+                // (fully unrolled: L == NG here, and across a loop back-edge hipcc's s_waitcnt insertion falls back to
+                // vmcnt(0), which would wait for the loads just issued for later steps)
+#pragma unroll
+                for (int s0 = 0; s0 < NG * NG; s0 += GP_DEPTH) {
 #pragma unroll
                     for (int k = 0; k < GP_DEPTH; ++k) {
                         const int st_ = s0 + k;
@@ -342,14 +348,14 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                         const int s_ = l * NG + c;
                         while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <= s_)
                             __builtin_amdgcn_s_sleep(1);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
                         const float *sp = samp + qi * GP_SLOT_FLOATS;
                         na = *reinterpret_cast<const float4 *>(sp + sub * 8);
                         nb = *reinterpret_cast<const float4 *>(sp + sub * 8 + 4);
                         nw = *reinterpret_cast<const float4 *>(sp + 16 + sub * 4);
                         const float2 r = *reinterpret_cast<const float2 *>(sp + 24);
                         nra = nrb = make_float4(r.x, r.y, r.x, r.y);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
                         if ((tid & 63) == 0) __hip_atomic_fetch_add(flags + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     float4 la = na, lb = nb, wa = nw;
