@@ -83,17 +83,14 @@ def relaunch_under_torchrun(a):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU,
     the driver's own command shape) and hand back their exit code.  With fewer GPUs than ranks (a 1-GPU test box) the
     ranks share GPUs and exchange through gloo, which stages CUDA tensors through the host -- RCCL wants one GPU per rank."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.device_count() < a.gpus:
         env.setdefault("MVDETR_DIST_BACKEND", "gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous picks the port (no bind-close-rebind race of a port chosen here)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={a.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -222,7 +219,7 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
         us, mn = time_launches(lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, gout, 64), launches)
         out["roofline_msda_bwd"] = roofline_entry(
             "msda_bwd_value_win + msda_bwd_sampling_resident (+ memset of grad_value)" if (D_ == 16 and N <= 7)
-            else "msda_bwd_value_win + msda_bwd_sampling_tile (+ memset of grad_value)", us, mn, bbytes, launches,
+            else "msda_bwd_value_win + msda_bwd_sampling_groups (+ memset of grad_value)", us, mn, bbytes, launches,
             "MultiScaleDeformableAttention.ms_deform_attn_backward (public contract), SURVEY 8d's locality-realistic input: "
             "bias grid + N(0, 1 px) offsets, softmax(N(0,1)) weights")
     return out
