@@ -127,7 +127,7 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
             // far from their queries (e.g. uniformly random locations) run the lane-group backward inside the first
             // launch instead -- no host synchronisation, no dependence on the caller's allocator
             int *hits = nullptr;
-            if (hipMallocAsync(reinterpret_cast<void **>(&hits), sizeof(int), st) != hipSuccess) hits = nullptr;
+            if (hipMallocAsync(reinterpret_cast<void **>(&hits), MSDA_PROBE_INTS * sizeof(int), st) != hipSuccess) hits = nullptr;
             int rc = hits ? msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits) : 0;
             if (!rc) rc = msda_backward_value_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, hits);
             if (!rc) rc = msda_backward_sampling_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_loc, grad_aw, hits);

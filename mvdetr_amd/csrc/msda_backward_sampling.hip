@@ -135,7 +135,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
         const int64_t q = (int64_t)b * S + lsi[lq] + (active ? (int64_t)qy * Wq + qx : 0);
         const int64_t e0 = (q * M + head) * L * P;            // this (query, head)'s first tap
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
-        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;   // (a slice holds two heads here: no per-head shift)
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
 
         float4 g[NV];
@@ -284,7 +284,9 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
         const int64_t q = (int64_t)b * S + lsi[cam] + (active ? (int64_t)qy * Wq + qx : 0);
         const int64_t e0 = (q * M + head) * L * P;            // this (query, head)'s first tap
         const float *vbatch = value + (int64_t)b * S * row + head * D;
-        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+        int shx, shy;                                         // where this head's taps lie (locality probe, msda_dispatch.h)
+        msda_probe_shift(local_hits, head, shx, shy);
+        const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
 
         [[maybe_unused]] const int tr = ((t - (int)blockIdx.x) / (int)gridDim.x) * 128 + (tid >> 6) * 16;
@@ -426,7 +428,9 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
         const int qy = Y0 + qly, qx = X0 + qlx;
         const bool in_level = qy < Hq && qx < Wq;
         const float *vbatch = value + (int64_t)b * S * row + head * D;
-        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+        int shx, shy;                                         // where this head's taps lie (locality probe, msda_dispatch.h)
+        msda_probe_shift(local_hits, head, shx, shy);
+        const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
 
         for (int g0 = 0; g0 < L; g0 += LG) {

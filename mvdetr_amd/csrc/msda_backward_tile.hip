@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
         const bool active = qy < Hq && qx < Wq;
         const int64_t cell = active ? (int64_t)qy * Wq + qx : 0;
         auto query = [&](int c) { return (int64_t)b * S + lsi[c] + cell; };
-        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+        int shx, shy;                                         // where this head's taps lie (locality probe)
+        msda_probe_shift(local_hits, head, shx, shy);
+        const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
         const int64_t level_base = ((int64_t)b * S + lsi[l]) * row;
         [[maybe_unused]] const int tr = ((t - (int)blockIdx.x) / (int)gridDim.x) * 64 + (tid >> 6) * 16;
@@ -345,30 +347,51 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
     }
 }
 
-// Samples MSDA_PROBE_SAMPLES taps spread over the whole call and counts those within MSDA_PROBE_RADIUS pixels of
-// their own query's cell (equal level shapes assumed; with unequal ones the count is ignored anyway).
+// Samples MSDA_PROBE_SAMPLES taps spread over the whole call -- block b samples head b % M -- and counts those within
+// MSDA_PROBE_RADIUS pixels of their own query's cell (equal level shapes assumed; with unequal ones the count is ignored
+// anyway); per head it also sums the displacement of the sampled taps from their cells (msda_dispatch.h).
 __global__ __launch_bounds__(256) void msda_locality_probe(const float *__restrict__ loc, const int64_t *__restrict__ shapes,
-                                                           int B, int S, int M, int L, int *__restrict__ hits)
+                                                           int B, int S, int M, int L, int *__restrict__ probe)
 {
+    __shared__ int red[4][3];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int H = (int)shapes[0], W = (int)shapes[1];
-    const int64_t taps = (int64_t)B * S * M * L * TILE_P;
-    // a fixed odd stride walks the tap index space evenly
-    const int64_t t = (int64_t)(((unsigned long long)i * 0x9E3779B97F4A7C15ull) % (unsigned long long)taps);
-    const int64_t bq = t / ((int64_t)M * L * TILE_P);
+    const int head = blockIdx.x % M;
+    const int64_t per_head = (int64_t)B * S * L * TILE_P;     // taps of one head
+    // a fixed odd stride walks the (query, level, point) space of the block's head evenly
+    const int64_t u = (int64_t)(((unsigned long long)i * 0x9E3779B97F4A7C15ull) % (unsigned long long)per_head);
+    const int64_t bq = u / ((int64_t)L * TILE_P);
+    const int64_t t = (bq * M + head) * L * TILE_P + (u - bq * L * TILE_P);
     const int cell = (int)((bq % S) % ((int64_t)H * W));
     const float x = loc[2 * t] * (float)W - 0.5f, y = loc[2 * t + 1] * (float)H - 0.5f;
-    const bool hit = i < MSDA_PROBE_SAMPLES && fabsf(x - (float)(cell % W)) <= MSDA_PROBE_RADIUS &&
-                     fabsf(y - (float)(cell / W)) <= MSDA_PROBE_RADIUS;
+    const float dx = x - (float)(cell % W), dy = y - (float)(cell / W);
+    const bool in = i < MSDA_PROBE_SAMPLES;
+    const bool hit = in && fabsf(dx) <= MSDA_PROBE_RADIUS && fabsf(dy) <= MSDA_PROBE_RADIUS;
+    const bool near = in && fabsf(dx) <= 16.f && fabsf(dy) <= 16.f;      // (NaN: false)
+    int sx = near ? (int)rintf(dx * 16.f) : 0, sy = near ? (int)rintf(dy * 16.f) : 0, sn = near ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, 64);
+        sy += __shfl_xor(sy, o, 64);
+        sn += __shfl_xor(sn, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sx; red[threadIdx.x >> 6][1] = sy; red[threadIdx.x >> 6][2] = sn; }
     const int n = __syncthreads_count(hit);
-    if (threadIdx.x == 0 && n) atomicAdd(hits, n);
+    if (threadIdx.x == 0) {
+        if (n) atomicAdd(probe, n);
+        if (head < MSDA_PROBE_MAXHEADS) {
+            atomicAdd(probe + 1 + 3 * head, red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+            atomicAdd(probe + 1 + 3 * head + 1, red[0][1] + red[1][1] + red[2][1] + red[3][1]);
+            atomicAdd(probe + 1 + 3 * head + 2, red[0][2] + red[1][2] + red[2][2] + red[3][2]);
+        }
+    }
 }
 
-int msda_launch_locality_probe(hipStream_t st, const float *loc, const int64_t *shapes, int B, int S, int M, int L, int *hits)
+int msda_launch_locality_probe(hipStream_t st, const float *loc, const int64_t *shapes, int B, int S, int M, int L, int *probe)
 {
-    hipError_t e = hipMemsetAsync(hits, 0, sizeof(int), st);
+    hipError_t e = hipMemsetAsync(probe, 0, MSDA_PROBE_INTS * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(msda_locality_probe, dim3(MSDA_PROBE_SAMPLES / 256), dim3(256), 0, st, loc, shapes, B, S, M, L, hits);
+    hipLaunchKernelGGL(msda_locality_probe, dim3(MSDA_PROBE_SAMPLES / 256), dim3(256), 0, st, loc, shapes, B, S, M, L, probe);
     return (int)hipGetLastError();
 }
 

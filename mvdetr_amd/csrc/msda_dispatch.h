@@ -52,10 +52,27 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
 int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                              float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits);
-// device-side locality probe shared by the two kernels: *hits = how many of MSDA_PROBE_SAMPLES sampled taps lie
-// within MSDA_PROBE_RADIUS pixels of their own query cell (stream-ordered; `hits` is a device int)
+// device-side locality probe shared by the kernels of a call (stream-ordered scratch of MSDA_PROBE_INTS ints):
+//   probe[0]              how many of MSDA_PROBE_SAMPLES sampled taps lie within MSDA_PROBE_RADIUS pixels of their own query cell
+//   probe[1 + 3 m + 0..2] for head m (< MSDA_PROBE_MAXHEADS): sum of the sampled taps' x / y displacement from their own cell in
+//                         1/16 px, and how many were summed (those within 16 px) -- where that head's taps lie.  MSDeformAttn's
+//                         offset bias is a ray per head (ms_deform_attn.py:64-69), so windows centred on the cell lose the
+//                         far points of the ray; the LDS-tiled backward kernels shift their windows by msda_probe_shift().
 #define MSDA_PROBE_SAMPLES 16384
 #define MSDA_PROBE_RADIUS 5.5f
+#define MSDA_PROBE_MAXHEADS 64
+#define MSDA_PROBE_INTS (1 + 3 * MSDA_PROBE_MAXHEADS)
+#define MSDA_PROBE_MAXSHIFT 3
+__device__ __forceinline__ void msda_probe_shift(const int *__restrict__ probe, int head, int &sx, int &sy)
+{
+    sx = sy = 0;
+    if (!probe || head >= MSDA_PROBE_MAXHEADS) return;
+    const int n = probe[1 + 3 * head + 2];
+    if (n <= 0) return;
+    const float inv = 1.f / (16.f * (float)n);
+    sx = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf((float)probe[1 + 3 * head] * inv)));
+    sy = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf((float)probe[1 + 3 * head + 1] * inv)));
+}
 int msda_launch_locality_probe(hipStream_t st, const float *loc, const int64_t *shapes, int B, int S, int M, int L, int *hits);
 
 // grad_sampling_loc / grad_attn_weight of the same calls from LDS-staged value windows (msda_backward_sampling.hip)

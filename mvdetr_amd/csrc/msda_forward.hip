@@ -126,7 +126,7 @@ static int forward_entry(void *stream, const T *value, const int64_t *shapes, co
             // A forced `tile` skips the probe (the kernel is then measured as it is).
             int *hits = nullptr;
             if (msda_fwd_impl_knob() == 0 &&
-                hipMallocAsync(reinterpret_cast<void **>(&hits), sizeof(int), st) != hipSuccess)
+                hipMallocAsync(reinterpret_cast<void **>(&hits), MSDA_PROBE_INTS * sizeof(int), st) != hipSuccess)
                 hits = nullptr;
             int rc = hits ? msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits) : 0;
             if (!rc) rc = msda_forward_tile(st, value, shapes, lsi, loc, aw, B, S, M, D, L, Lq, P, out, hits);

@@ -129,9 +129,54 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
             miss[c] = 0;
         }
 
+        // Window centre (round 3): the taps of a slice's heads are not centred on the query cell -- MSDeformAttn's offset
+        // bias is a ray per head (ms_deform_attn.py:64-69: 1..4 px along the head's direction), so with +-6 px windows around
+        // the cell the far points of a ray leave the window as soon as the learned part adds a pixel or two, and every
+        // such tap is a serialised global gather at the end of the job.  The tile measures where its taps lie -- the mean
+        // displacement of the first camera's first-level taps from their own cells -- and shifts all of the job's windows
+        // by that (rounded, at most +-3 px; the same for every level: the bias does not depend on the level).
+        int shift_x = 0, shift_y = 0;
+        if constexpr (SPLIT == 1) {
+            float sx = 0.f, sy = 0.f, sn = 0.f;
+            if (active) {
+                const int64_t cq = cam_q(cam0);
+                const float *lp = lp0 + cq * lay.q_l;
+                const float4 a0 = *reinterpret_cast<const float4 *>(lp), b0 = *reinterpret_cast<const float4 *>(lp + 4);
+                float mx = 0.25f * ((a0.x + a0.z) + (b0.x + b0.z)), my = 0.25f * ((a0.y + a0.w) + (b0.y + b0.w));
+                if constexpr (FUSED) {
+                    // raw offsets are already pixels relative to the reference point; that point relative to the cell:
+                    const float *rp = rp0 + (cq - (int64_t)b * S) * lay.r_q;
+                    const float rx = FUSED == 2 ? rp[0] : 0.25f * ((rp[0] + rp[2]) + (rp[4] + rp[6]));
+                    const float ry = FUSED == 2 ? rp[1] : 0.25f * ((rp[1] + rp[3]) + (rp[5] + rp[7]));
+                    mx += rx * fW - 0.5f - (float)qx;
+                    my += ry * fH - 0.5f - (float)qy;
+                } else {
+                    mx = mx * fW - 0.5f - (float)qx;
+                    my = my * fH - 0.5f - (float)qy;
+                }
+                if (mx == mx && my == my && fabsf(mx) < 64.f && fabsf(my) < 64.f) { sx = mx; sy = my; sn = 1.f; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sx += __shfl_xor(sx, o, 64);
+                sy += __shfl_xor(sy, o, 64);
+                sn += __shfl_xor(sn, o, 64);
+            }
+            float *red = win + WH * WW * SLICE;               // (behind the window: the launch reserves the fallback body's larger one)
+            __syncthreads();                                  // the previous job is done with it
+            if ((tid & 63) == 0) { red[(tid >> 6) * 4] = sx; red[(tid >> 6) * 4 + 1] = sy; red[(tid >> 6) * 4 + 2] = sn; }
+            __syncthreads();
+            float tx = 0.f, ty = 0.f, tn = 0.f;
+            for (int wv = 0; wv < Cfg::THREADS / 64; ++wv) { tx += red[wv * 4]; ty += red[wv * 4 + 1]; tn += red[wv * 4 + 2]; }
+            if (tn > 0.f && !(FUSED && local_hits == reinterpret_cast<const int *>(8))) {
+                shift_x = max(-3, min(3, (int)rintf(tx / tn)));
+                shift_y = max(-3, min(3, (int)rintf(ty / tn)));
+            }
+        }
+
         for (int l = 0; l < L; ++l) {
-            // window of level l around the tile (all levels have the query level's shape)
-            const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;
+            // window of level l around the tile (all levels have the query level's shape), shifted to where the taps are
+            const int oy = Y0 + TH / 2 - WH / 2 + shift_y, ox = X0 + TW / 2 - WW / 2 + shift_x;
             const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
             __syncthreads();                                  // everyone is done reading the old window
             if constexpr (DMA) {
@@ -377,6 +422,10 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits)
 {
+    // MVDETR_MSDA_WINDOW_SHIFT=0: keep the fused kernels' windows centred on the tile (A/B knob; the fused entries have no
+    // locality probe, so their `local_hits` argument carries the flag)
+    static const bool no_shift = [] { const char *e = getenv("MVDETR_MSDA_WINDOW_SHIFT"); return e && e[0] == '0'; }();
+    if (fused && no_shift) local_hits = reinterpret_cast<const int *>(8);
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits
     if (L >= 9 && L <= 16) {           // many cameras: 4 lane groups x up to 4 cameras (NG is the template's loop bound)
         switch ((D == 32 ? 100 : 0) + L) {
