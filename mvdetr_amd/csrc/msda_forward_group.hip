@@ -137,22 +137,27 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         // by that (rounded, at most +-3 px; the same for every level: the bias does not depend on the level).
         int shift_x = 0, shift_y = 0;
         if constexpr (SPLIT == 1) {
+            // every wave looks at the SAME sample -- the tile's first 32 cells x the slice's two halves, camera 0, level 0 --
+            // so all waves arrive at the same shift without exchanging anything (no LDS, no barrier)
+            const int sl = tid & 63, s_sub = sl & 1, s_qi = sl >> 1;
+            const int s_qy = Y0 + s_qi / TW, s_qx = X0 + s_qi % TW;
+            const int s_head = (hs * SLICE + s_sub * LCH) / D;
             float sx = 0.f, sy = 0.f, sn = 0.f;
-            if (active) {
-                const int64_t cq = cam_q(cam0);
-                const float *lp = lp0 + cq * lay.q_l;
+            if (s_qy < Hq && s_qx < Wq) {
+                const int64_t s_cell = (int64_t)s_qy * Wq + s_qx, cq = cam_q(0);
+                const float *lp = off + (cq + s_cell) * lay.q_l + lay.head_l(s_head);
                 const float4 a0 = *reinterpret_cast<const float4 *>(lp), b0 = *reinterpret_cast<const float4 *>(lp + 4);
                 float mx = 0.25f * ((a0.x + a0.z) + (b0.x + b0.z)), my = 0.25f * ((a0.y + a0.w) + (b0.y + b0.w));
                 if constexpr (FUSED) {
                     // raw offsets are already pixels relative to the reference point; that point relative to the cell:
-                    const float *rp = rp0 + (cq - (int64_t)b * S) * lay.r_q;
+                    const float *rp = ref + b * ref_bstride + (cq - (int64_t)b * S + s_cell) * lay.r_q;
                     const float rx = FUSED == 2 ? rp[0] : 0.25f * ((rp[0] + rp[2]) + (rp[4] + rp[6]));
                     const float ry = FUSED == 2 ? rp[1] : 0.25f * ((rp[1] + rp[3]) + (rp[5] + rp[7]));
-                    mx += rx * fW - 0.5f - (float)qx;
-                    my += ry * fH - 0.5f - (float)qy;
+                    mx += rx * fW - 0.5f - (float)s_qx;
+                    my += ry * fH - 0.5f - (float)s_qy;
                 } else {
-                    mx = mx * fW - 0.5f - (float)qx;
-                    my = my * fH - 0.5f - (float)qy;
+                    mx = mx * fW - 0.5f - (float)s_qx;
+                    my = my * fH - 0.5f - (float)s_qy;
                 }
                 if (mx == mx && my == my && fabsf(mx) < 64.f && fabsf(my) < 64.f) { sx = mx; sy = my; sn = 1.f; }
             }
@@ -162,12 +167,10 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                 sy += __shfl_xor(sy, o, 64);
                 sn += __shfl_xor(sn, o, 64);
             }
-            float *red = win + WH * WW * SLICE;               // (behind the window: the launch reserves the fallback body's larger one)
-            __syncthreads();                                  // the previous job is done with it
-            if ((tid & 63) == 0) { red[(tid >> 6) * 4] = sx; red[(tid >> 6) * 4 + 1] = sy; red[(tid >> 6) * 4 + 2] = sn; }
-            __syncthreads();
-            float tx = 0.f, ty = 0.f, tn = 0.f;
-            for (int wv = 0; wv < Cfg::THREADS / 64; ++wv) { tx += red[wv * 4]; ty += red[wv * 4 + 1]; tn += red[wv * 4 + 2]; }
+            // (the butterfly leaves every lane with the same sums only up to the order of the additions: take lane 0's)
+            const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
+            const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy)));
+            const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
             if (tn > 0.f && !(FUSED && local_hits == reinterpret_cast<const int *>(8))) {
                 shift_x = max(-3, min(3, (int)rintf(tx / tn)));
                 shift_y = max(-3, min(3, (int)rintf(ty / tn)));

@@ -8,13 +8,16 @@ namespace mvdetr {
 constexpr int TILE_MAX_LEVELS = 16;     // 64-bit miss mask = L * P bits with P == 4
 constexpr int TILE_P = 4;
 
-template <int D_, int SLICE_, int TH_, int TW_, int R_, int THREADS_ = TH_ * TW_ * 2> struct TileCfg {
-    static constexpr int D = D_, TH = TH_, TW = TW_, R = R_;
+// R_: halo in x (and in y unless RY_ is given).  The LDS-DMA window copies start every window row at a wave-uniform LDS
+// base; rows of WW * SLICE * 4 bytes that are not multiples of 512 bytes (WW = 26 at R = 5) fault on gfx950, so a narrower
+// halo is only available in y.
+template <int D_, int SLICE_, int TH_, int TW_, int R_, int THREADS_ = TH_ * TW_ * 2, int RY_ = R_> struct TileCfg {
+    static constexpr int D = D_, TH = TH_, TW = TW_, R = R_, RY = RY_;
     static constexpr int SLICE = SLICE_;              // floats of a token row staged per workgroup (32 = 128 B, 16 = 64 B)
     static constexpr int SUBS = 2;                    // lanes per query, each owning half a slice
     static constexpr int NV = SLICE / SUBS / 4;       // 16-byte chunks (float4 accumulators) per lane
     static constexpr int PARTS = SLICE / 4;           // float4 per token in LDS
-    static constexpr int WH = TH + 2 * R, WW = TW + 2 * R;
+    static constexpr int WH = TH + 2 * RY, WW = TW + 2 * R;
     static constexpr int THREADS = THREADS_;          // >= TH*TW*SUBS compute lanes; the surplus only helps the window copy
     static_assert(THREADS_ >= TH_ * TW_ * 2 && THREADS_ % 64 == 0, "whole waves covering the tile");
     static constexpr int COLSLOTS = THREADS / PARTS;  // window columns a copy pass covers ...
