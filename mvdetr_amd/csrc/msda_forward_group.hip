@@ -134,9 +134,10 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         // the cell the far points of a ray leave the window as soon as the learned part adds a pixel or two, and every
         // such tap is a serialised global gather at the end of the job.  The tile measures where its taps lie -- the mean
         // displacement of the first camera's first-level taps from their own cells -- and shifts all of the job's windows
-        // by that (rounded, at most +-3 px; the same for every level: the bias does not depend on the level).
+        // by that (rounded, at most +-3 px; the same for every level: the bias does not depend on the level).  Any shift
+        // gives the same results -- taps outside the window are gathered from memory -- it only decides how many do.
         int shift_x = 0, shift_y = 0;
-        if constexpr (SPLIT == 1) {
+        {
             // every wave looks at the SAME sample -- the tile's first 32 cells x the slice's two halves, camera 0, level 0 --
             // so all waves arrive at the same shift without exchanging anything (no LDS, no barrier)
             const int sl = tid & 63, s_sub = sl & 1, s_qi = sl >> 1;
