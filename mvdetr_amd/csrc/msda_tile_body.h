@@ -137,12 +137,58 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
         for (int i = 0; i < 2 * NV; ++i) acc[i] = (float2v){0.f, 0.f};
         unsigned long long miss = 0ull;
 
-        // window geometry of a level: origin = the tile's centre carried to that level (integers)
+        // Where the tile's taps lie (round 3, as in msda_forward_group.hip): MSDeformAttn's offset bias is a ray per head, so
+        // the far points of a ray leave a window centred on the tile as soon as the learned part adds a pixel or two, and each
+        // such tap is a serialised global gather.  Every wave looks at the SAME sample -- the tile's first 32 cells x the
+        // slice's two halves, source level 0 -- and arrives at the same shift (in pixels of the query level, at most +-3)
+        // without exchanging anything.  Any shift gives the same results; it only decides how many taps miss the window.
+        int shift_x = 0, shift_y = 0;
+        {
+            const int sl = tid & 63, s_sub = sl & 1, s_qi = sl >> 1;
+            const int s_qy = Y0 + s_qi / TW, s_qx = X0 + s_qi % TW;
+            const int s_head = (hs * SLICE + s_sub * LCH) / D;
+            const int64_t s_q = lsi[lq] - q_first + (int64_t)s_qy * Wq + s_qx;
+            const float W0 = (float)shapes[1], H0 = (float)shapes[0];
+            float sx = 0.f, sy = 0.f, sn = 0.f;
+            if (s_qi < TH * TW && s_qy < Hq && s_qx < Wq && s_q < Lq) {
+                const float *slp = loc + ((int64_t)b * Lq + s_q) * lay.q_l + lay.head_l(s_head);
+                const float4 a0 = *reinterpret_cast<const float4 *>(slp), b0 = *reinterpret_cast<const float4 *>(slp + 4);
+                float mx = 0.25f * ((a0.x + a0.z) + (b0.x + b0.z)), my = 0.25f * ((a0.y + a0.w) + (b0.y + b0.w));
+                if constexpr (FUSED) {
+                    const float *srp = ref + b * ref_bstride + s_q * lay.r_q;
+                    const float rx = FUSED == 2 ? srp[0] : 0.25f * ((srp[0] + srp[2]) + (srp[4] + srp[6]));
+                    const float ry = FUSED == 2 ? srp[1] : 0.25f * ((srp[1] + srp[3]) + (srp[5] + srp[7]));
+                    mx += rx * W0 - 0.5f;                     // raw offsets are pixels of the sampled level
+                    my += ry * H0 - 0.5f;
+                } else {
+                    mx = mx * W0 - 0.5f;
+                    my = my * H0 - 0.5f;
+                }
+                // displacement from the cell's own position carried to level 0, in pixels of the query level
+                mx = (mx - (((float)s_qx + 0.5f) * W0 / (float)Wq - 0.5f)) * (float)Wq / W0;
+                my = (my - (((float)s_qy + 0.5f) * H0 / (float)Hq - 0.5f)) * (float)Hq / H0;
+                if (mx == mx && my == my && fabsf(mx) < 64.f && fabsf(my) < 64.f) { sx = mx; sy = my; sn = 1.f; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sx += __shfl_xor(sx, o, 64);
+                sy += __shfl_xor(sy, o, 64);
+                sn += __shfl_xor(sn, o, 64);
+            }
+            const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
+            const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy)));
+            const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
+            if (tn > 0.f) {
+                shift_x = max(-3, min(3, (int)rintf(tx / tn)));
+                shift_y = max(-3, min(3, (int)rintf(ty / tn)));
+            }
+        }
+        // window geometry of a level: origin = the tile's centre (+ the shift) carried to that level (integers)
         auto origin = [&](int l, int &oy, int &ox, int &H, int &W) {
             H = (int)shapes[2 * l];
             W = (int)shapes[2 * l + 1];
-            oy = (2 * Y0 + TH) * H / (2 * Hq) - WH / 2;
-            ox = (2 * X0 + TW) * W / (2 * Wq) - WW / 2;
+            oy = (2 * (Y0 + shift_y) + TH) * H / (2 * Hq) - WH / 2;
+            ox = (2 * (X0 + shift_x) + TW) * W / (2 * Wq) - WW / 2;
         };
         // issue this thread's share of a window copy into registers (loads stay in flight): its
         // column, every ROWS_PER_PASS-th row
