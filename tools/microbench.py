@@ -91,8 +91,17 @@ def bench_msda(a, L, H, W, M, D, P, B, S, fwd_bytes, bwd_bytes):
     g = torch.Generator().manual_seed(0)
     ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
     ref = torch.stack([xs / W, ys / H], -1).reshape(1, H * W, 1, 1, 2).repeat(1, L, L, P, 1).cuda()
-    raw = torch.randn(B, S, L * M * P * 3, generator=g).cuda()          # [offsets | logits], level-major
+    raw = torch.randn(B, S, L * M * P * 3, generator=g)                  # [offsets | logits], level-major
     n_off = L * M * P * 2
+    # SURVEY 8d's locality-realistic input for the fused entry too: offsets = the module's initial bias grid
+    # (ms_deform_attn.py:64-69: head m's ray, point p at (p + 1) px) + N(0, 1 px); logits N(0, 1)
+    import math
+    ang = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+    dirs = torch.stack([ang.cos(), ang.sin()], -1)
+    dirs = dirs / dirs.abs().max(-1, keepdim=True)[0]
+    bias = dirs.view(1, M, 1, 2) * torch.arange(1, P + 1, dtype=torch.float32).view(1, 1, P, 1)      # [1, M, P, 2]
+    raw[..., :n_off] += bias.expand(L, M, P, 2).reshape(-1)
+    raw = raw.cuda()
     off, logit = raw[..., :n_off].unflatten(-1, (L, M, P, 2)), raw[..., n_off:].unflatten(-1, (L, M, P))
     value, shapes, lsi = [x.cuda() for x in encoder_msda_inputs(L, H, W, M, D, P, B=B, seed=0)[:3]]
     fn = lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, ref, off, logit, level_major=True)  # noqa: E731
