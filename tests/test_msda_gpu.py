@@ -930,3 +930,55 @@ def test_half_backward_is_refused(ops):
         MSDA.ms_deform_attn_backward(*args, go, 64)
     with pytest.raises(RuntimeError, match="not implemented"):        # the host path is float/double only
         MSDA.ms_deform_attn_forward(v.half(), s, lsi, loc.half(), aw.half(), 64)
+
+
+# ---- windows that follow the taps (round 3) ------------------------------------------------------------------------------
+def _window_shift_case(scale):
+    """Fused module forward on offsets = scale x the reference's bias grid (rays of up to 4 * scale px) + learned noise:
+    with scale 1.5 the far points of every ray sit at the edge of a +-6 px window."""
+    L, H, W, d_model, M, P = 7, 24, 40, 128, 8, 4
+    mod = _module_with_random_projections(d_model, L, M, P, seed=3).eval()
+    with torch.no_grad():
+        mod.sampling_offsets.bias.mul_(scale)
+    shapes = torch.tensor([[H, W]] * L)
+    S = L * H * W
+    g = torch.Generator().manual_seed(17)
+    query, src = torch.randn(1, S, d_model, generator=g), torch.randn(1, S, d_model, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)[None]
+    return mod, query, ref, src, shapes
+
+
+@pytest.mark.parametrize("scale", [1.0, 1.5, 2.5])
+def test_window_shift_gives_the_same_results_as_centred_windows(ops, scale):
+    """The forward kernels centre their LDS windows on where the tile's taps lie (msda_forward_group.hip, msda_tile_body.h).
+    Any shift must give the oracle's result -- taps outside the window are gathered from memory -- and the same result as
+    MVDETR_MSDA_WINDOW_SHIFT=0 (read once per process: the centred run is a child process)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    mod, query, ref, src, shapes = _window_shift_case(scale)
+    md = mod.cuda()
+    with torch.no_grad():
+        got = md(query.cuda(), ref.cuda(), src.cuda(), shapes.cuda(), level_start_index(shapes).cuda()).cpu()
+        md.fused_inference = False
+        unfused = md(query.cuda(), ref.cuda(), src.cuda(), shapes.cuda(), level_start_index(shapes).cuda()).cpu()
+    params = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+    want = torch_oracle.msda_module(params, query, ref, src, shapes, 8, 4)
+    assert (got - want).abs().max().item() < FP32_TOL and (unfused - want).abs().max().item() < FP32_TOL
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "centred.pt")
+        code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "from test_msda_gpu import _window_shift_case, level_start_index\n"
+                "mod, query, ref, src, shapes = _window_shift_case(%r)\n"
+                "md = mod.cuda()\n"
+                "with torch.no_grad():\n"
+                "    y = md(query.cuda(), ref.cuda(), src.cuda(), shapes.cuda(), level_start_index(shapes).cuda()).cpu()\n"
+                "torch.save(y, %r)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                          os.path.dirname(os.path.abspath(__file__)), scale, out)
+        env = dict(os.environ, MVDETR_MSDA_WINDOW_SHIFT="0")
+        subprocess.run([sys.executable, "-c", code], env=env, check=True, timeout=300)
+        centred = torch.load(out)
+    assert (centred - want).abs().max().item() < FP32_TOL
+    assert (centred - got).abs().max().item() < 2e-5
