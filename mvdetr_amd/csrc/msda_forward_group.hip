@@ -25,6 +25,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef MVDETR_SHIFT_MAX
+#define MVDETR_SHIFT_MAX 3
+#endif
+
 namespace mvdetr {
 
 __device__ __forceinline__ void gfma4(float2v &lo, float2v &hi, float w, const float4 &c)
@@ -173,8 +177,8 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
             const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy)));
             const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
             if (tn > 0.f && !(FUSED && local_hits == reinterpret_cast<const int *>(8))) {
-                shift_x = max(-3, min(3, (int)rintf(tx / tn)));
-                shift_y = max(-3, min(3, (int)rintf(ty / tn)));
+                shift_x = max(-MVDETR_SHIFT_MAX, min(MVDETR_SHIFT_MAX, (int)rintf(tx / tn)));
+                shift_y = max(-MVDETR_SHIFT_MAX, min(MVDETR_SHIFT_MAX, (int)rintf(ty / tn)));
             }
         }
 
