@@ -378,7 +378,8 @@ def main():
         frames_per_step, scaling = world * Bf, "weak"
 
     tuning_shared = None
-    if world > 1 and gemm_tuning:
+    if world > 1 and gemm_tuning and a.parallel == "dp":
+        # (dp only: a view-sharded step has collectives in it, rank 0 cannot run it alone)
         # rank 0 warms up first: TunableOp's measured GEMM picks go to ONE results file and MIOpen's find results to its
         # user database; the other ranks then read both instead of each spending its warm-up measuring the same shapes.
         # Every rank runs the same barrier sequence whatever fails in between.
