@@ -15,7 +15,8 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libmvdetr_ops.so")
+# MVDETR_OPS_LIB: another build of the same sources (the phase-stamp build libmvdetr_ops_trace.so of tools/experiments)
+LIB_PATH = os.environ.get("MVDETR_OPS_LIB") or os.path.join(CSRC, "libmvdetr_ops.so")
 ABI_VERSION = 9
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int

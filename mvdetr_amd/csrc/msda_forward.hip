@@ -214,8 +214,10 @@ int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const
         return (int)hipErrorInvalidValue;
     // bit 0 level-major raw tensors, bit 1 one reference point per (query, level), bit 2 slice-interleaved raw tensor
     // (offsets and logits in one run per (query, slice, level); excludes bit 0), bit 3 level-major reference points
-    // [.., L, Lq, 2] (needs bit 1)
-    if ((level_major & ~15) || ((level_major & 4) && (level_major & 1)) || ((level_major & 8) && !(level_major & 2)))
+    // [.., L, Lq, 2] (needs bit 1), bit 4 the slice-interleaved tensor with the LEVEL outermost, [.., Lq, L, M/g, run]
+    // (needs bit 2)
+    if ((level_major & ~31) || ((level_major & 4) && (level_major & 1)) || ((level_major & 8) && !(level_major & 2)) ||
+        ((level_major & 16) && !(level_major & 4)))
         return (int)hipErrorInvalidValue;
     if (level_major & 4) {
         // the two pointers address one tensor: logits start behind the slice's offsets

@@ -117,7 +117,7 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
     const SamplingLayout lay = plain_layout(M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P);     // [.., Lq, M, L, P(, 2)]
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
-    if (msda_group_supported(D, L) && !narrow_slices())
+    if (msda_group_supported(D, L) && msda_group_fits(S, M * D, lay) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
     return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out, local_hits);
 }
@@ -136,8 +136,15 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     if (slice_major) {
         // one tensor [.., Lq, M / hps, L, (hps x P x 2 offsets | hps x P logits)]: what the workgroup of a 128-byte
         // slice reads for a (query, level) is one contiguous run of hps * 12 floats; `logits` = `offsets` + hps * 8
+        // Bit 4: the level is the OUTER index, [.., Lq, L, M / hps, run] -- a (query, level)'s runs of all slices are then
+        // M / hps * chunk * 4 = 384 contiguous bytes = three whole 128-byte lines (at D = 16, M = 8), shared by the four
+        // slice jobs of a tile, which run at the same time on one XCD (one L2); with the slice outermost a run shares its
+        // lines with the same slice's NEXT level, i.e. with a later phase of the same job, by when the line has left L2.
         const int hps = 32 / D, chunk = hps * P * 3;
-        lay = SamplingLayout{qstride_l, P * 2, chunk, qstride_w, P, chunk, hps, L * chunk, L * chunk, r_q, r_l};
+        if (layout & 16)
+            lay = SamplingLayout{qstride_l, P * 2, (M / hps) * chunk, qstride_w, P, (M / hps) * chunk, hps, chunk, chunk, r_q, r_l};
+        else
+            lay = SamplingLayout{qstride_l, P * 2, chunk, qstride_w, P, chunk, hps, L * chunk, L * chunk, r_q, r_l};
     } else if (level_major) {
         lay = plain_layout(qstride_l, P * 2, M * P * 2, qstride_w, P, M * P, r_q, r_l);              // [.., Lq, L, M, P(, 2)]
     } else {
@@ -148,7 +155,7 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     // A query-sharded call (a rank's own cameras as queries, mvdetr_amd/dist.py) has too few query levels per
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
-    if (all_levels && msda_group_supported(D, L) && !narrow_slices())
+    if (all_levels && msda_group_supported(D, L) && msda_group_fits(S, M * D, lay) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
                                   M, D, L, out);
     return shared_ref ? dispatch_tile<2>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,

@@ -72,12 +72,24 @@ struct QueryLevels {
 
 // camera-grouped fused forward (msda_forward_group.hip)
 bool msda_group_supported(int D, int L);
+// its per-lane addresses are 32-bit float offsets from per-batch, per-camera bases: one batch element's sampling tensors,
+// reference points and output must each stay below 2^32 bytes (anything larger runs the tile kernel: 64-bit addresses)
+inline bool msda_group_fits(int S, int row, const SamplingLayout &lay)
+{
+    const int64_t lim = (int64_t)1 << 30;                   // floats
+    return (int64_t)S * lay.q_l < lim && (int64_t)S * lay.q_w < lim && (int64_t)S * lay.r_q < lim && (int64_t)S * row < lim;
+}
 // fused: 0 = final locations / weights (ref unused), 1 = raw + reference points [.., Lq, L, P, 2], 2 = raw + one
 // reference point per (query, level) [.., Lq, L, 2]
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out,
                        const int *local_hits = nullptr);
+// its many-camera instantiations (msda_forward_group_many.hip); `opts`: GROUP_OPT_* of msda_group_kernel.h
+int msda_forward_group_many(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
+                            const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
+                            SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits,
+                            int opts);
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
 // scalar registers).

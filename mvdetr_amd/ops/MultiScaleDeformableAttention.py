@@ -127,7 +127,8 @@ def fused_supported_dims(B, S, M, D, num_levels, num_query, num_point, query_lev
 
 
 def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, reference_points, sampling_offsets,
-                                 attn_logits, level_major=False, query_levels=None, *, raw=None, ref_level_major=False):
+                                 attn_logits, level_major=False, query_levels=None, *, raw=None, ref_level_major=False,
+                                 raw_level_outer=False):
     """Core + the module arithmetic around it (ms_deform_attn.py:100-107) in one kernel (inference):
     value [B,S,M,D]; reference_points [B or 1, Lq, L, P, 2] (may be a batch-expanded view), or [B or 1, Lq, L, 2]
     when the P sampling points of a (query, level) share one reference point (MVDeTr's map: P identical copies) --
@@ -136,7 +137,8 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
     ([B,Lq,L,M,P,2] / [B,Lq,L,M,P] with ``level_major``); each may be a column block of a wider GEMM
     output (dense per query, arbitrary query stride).  Alternatively ``raw`` [B, Lq, M/g * L * 12g] holds both,
     slice-interleaved (g = 32/D heads per 128-byte slice of the token row; per (query, slice, level): g*P*2 offsets
-    then g*P logits -- see slice_major_rows()); sampling_offsets / attn_logits are then None.  -> [B, Lq, M*D].
+    then g*P logits -- see slice_major_rows()); sampling_offsets / attn_logits are then None; ``raw_level_outer``: the same
+    runs ordered [B, Lq, L, M/g, 12g] (level outermost).  -> [B, Lq, M*D].
     ``query_levels=(l0, l1)``: the Lq queries are the tokens of levels l0..l1-1 only (one rank's cameras in a
     query-sharded encoder, mvdetr_amd/dist.py); value still holds every level.
     No extension counterpart in the reference: this is SURVEY row f1."""
@@ -157,8 +159,10 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
         g = 32 // D
         off_ptr, logit_ptr = raw.data_ptr(), raw.data_ptr() + g * P * 2 * raw.element_size()
         qstrides = [raw.stride(1), raw.stride(1)]
-        flags |= 4
+        flags |= 4 | (16 if raw_level_outer else 0)
     else:
+        if raw_level_outer:
+            raise RuntimeError("raw_level_outer describes the slice-interleaved raw tensor")
         Lq, P = sampling_offsets.shape[1], sampling_offsets.shape[4]
         if tuple(sampling_offsets.shape[2:4]) != ((L, M) if level_major else (M, L)):
             raise RuntimeError("sampling_offsets layout does not match level_major")
@@ -199,22 +203,30 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
     return out
 
 
-def slice_major_rows(M, L, P, D):
+def slice_major_rows(M, L, P, D, level_outer=False):
     """Row order of the ONE Linear that produces the slice-interleaved ``raw`` tensor from the reference module's two:
     (rows of sampling_offsets.weight, rows of attention_weights.weight shifted by M*L*P*2), i.e. indices into
     cat([sampling_offsets.weight, attention_weights.weight]).  Reference row orders: offsets (m, l, p, xy),
-    logits (m, l, p) -- ms_deform_attn.py:99-101."""
+    logits (m, l, p) -- ms_deform_attn.py:99-101.  Runs (one per slice and level: g heads' offsets, then their logits)
+    ordered slice-major [M/g, L] or, ``level_outer``, level-major [L, M/g]."""
     g = 32 // D
     n_off = M * L * P * 2
+
+    def run(s, l):
+        r = []
+        for h in range(g):
+            m = s * g + h
+            r += [((m * L + l) * P + p) * 2 + xy for p in range(P) for xy in range(2)]
+        for h in range(g):
+            m = s * g + h
+            r += [n_off + (m * L + l) * P + p for p in range(P)]
+        return r
+
+    pairs = [(s, l) for l in range(L) for s in range(M // g)] if level_outer else \
+            [(s, l) for s in range(M // g) for l in range(L)]
     rows = []
-    for s in range(M // g):
-        for l in range(L):
-            for h in range(g):
-                m = s * g + h
-                rows += [((m * L + l) * P + p) * 2 + xy for p in range(P) for xy in range(2)]
-            for h in range(g):
-                m = s * g + h
-                rows += [n_off + (m * L + l) * P + p for p in range(P)]
+    for s, l in pairs:
+        rows += run(s, l)
     return rows
 
 

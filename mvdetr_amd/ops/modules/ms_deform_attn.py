@@ -8,6 +8,7 @@ extension through MSDeformAttnFunction.
 from __future__ import annotations
 
 import math
+import os
 import warnings
 import weakref
 
@@ -52,6 +53,8 @@ class MSDeformAttn(nn.Module):
         self._cache_projection = False
         self._fused_cache = None
         self._fused_rows = None
+        # order of the fused path's raw tensor: runs [L, M/g] (level outermost) or [M/g, L] -- see slice_major_rows
+        self.raw_level_outer = os.environ.get("MVDETR_MSDA_RAW_LAYOUT", "level") != "slice"
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -89,7 +92,8 @@ class MSDeformAttn(nn.Module):
             return self._fused_cache
         dev = self.sampling_offsets.weight.device
         if self._fused_rows is None or self._fused_rows.device != dev:
-            rows = MSDA.slice_major_rows(self.n_heads, self.n_levels, self.n_points, self.d_model // self.n_heads)
+            rows = MSDA.slice_major_rows(self.n_heads, self.n_levels, self.n_points, self.d_model // self.n_heads,
+                                         level_outer=self.raw_level_outer)
             self._fused_rows = torch.tensor(rows, dtype=torch.long, device=dev)
         with torch.no_grad():
             w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).index_select(0, self._fused_rows)
@@ -190,7 +194,7 @@ class MSDeformAttn(nn.Module):
                 out = MSDA.ms_deform_attn_forward_fused(
                     value, input_spatial_shapes, input_level_start_index,
                     reference_points if shared is None else shared, None, None, query_levels=query_levels, raw=raw,
-                    ref_level_major=shared is not None)
+                    ref_level_major=shared is not None, raw_level_outer=self.raw_level_outer)
                 return self.output_proj(out)
             # odd storage offsets: the reference arithmetic on the same raw values
             n_off = self.n_heads * self.n_levels * self.n_points * 2

@@ -844,7 +844,13 @@ def test_fused_slice_interleaved_layout_equals_the_plain_layouts(ops, lv, D, M, 
     # a wider GEMM output whose leading columns are the raw tensor
     wide = torch.cat([raw, torch.randn(B, Lq, 8, generator=g)], -1).cuda()
     c = MSDA.ms_deform_attn_forward_fused(*dv, ref.cuda(), None, None, raw=wide, **kw)
-    for got in (a, b, c):
+    # the same runs with the level outermost, [.., Lq, L, M/g, run] (what the module produces since round 4)
+    rows_lo = torch.tensor(MSDA.slice_major_rows(M, L, P, D, level_outer=True))
+    raw_lo = torch.cat([off.reshape(B, Lq, -1), logit.reshape(B, Lq, -1)], -1).index_select(-1, rows_lo).contiguous()
+    assert sorted(rows_lo.tolist()) == sorted(rows.tolist()) == list(range(M * L * P * 3))
+    d = MSDA.ms_deform_attn_forward_fused(*dv, ref.transpose(1, 2).contiguous().cuda(), None, None, raw=raw_lo.cuda(),
+                                          ref_level_major=True, raw_level_outer=True, **kw)
+    for got in (a, b, c, d):
         assert (got - plain).abs().max().item() < 2e-5
     loc = torch_oracle.msda_sampling_locations(ref[:, :, :, None, :].expand(B, Lq, L, P, 2), off, shapes)
     want = torch_oracle.msda_core(value, shapes, loc, torch.softmax(logit.flatten(-2), -1).view_as(logit))
