@@ -40,6 +40,10 @@ static int group_opts(int fused)
 __device__ unsigned long long *g_group_trace = nullptr;
 #endif
 
+// reads in flight ahead of the FMAs in msda_fwd_group2's tap stream, in pairs (measured at Wildtrack size: 2 and 3 alike, 4
+// slower -- registers)
+constexpr int GROUP2_DEPTH = 2;
+
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits)
@@ -49,25 +53,15 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
     if (L >= 9 && L <= 16)             // many cameras: 4 lane groups x up to 4 cameras (msda_forward_group_many.hip)
         return msda_forward_group_many(st, value, shapes, lsi, off, logit, ref, ref_bstride, fused, lay, B, S, M, D, L, out,
                                        local_hits, opts);
-    // fused entries copy their windows with LDS-DMA (measured at Wildtrack size: 136 -> 127 us; the public contract's
-    // kernel is a shade slower with it, 172 -> 174 us, and keeps the register-staged copy)
-    if (D == 16 && L == 7 && fused == 2) {
-        // round-4 A/B: compile-time variants of the benchmarked instantiation (MVDETR_MSDA_GROUP_VAR; 1x = two camera groups)
-        static const int var = [] { const char *e = getenv("MVDETR_MSDA_GROUP_VAR"); return e ? atoi(e) : 0; }();
-        switch (var) {
-        case 1: return launch_group<GWide16, 7, 2, 2, 1, true, 1>(GROUP_ARGS);
-        case 2: return launch_group<GWide16, 7, 2, 2, 1, true, 2>(GROUP_ARGS);
-        case 3: return launch_group<GWide16, 7, 2, 2, 1, true, 3>(GROUP_ARGS);
-        case 22: return launch_group2<GWide16, 7, 2, 2>(GROUP_ARGS);
-        case 23: return launch_group2<GWide16, 7, 2, 3>(GROUP_ARGS);
-        case 24: return launch_group2<GWide16, 7, 2, 4>(GROUP_ARGS);
-        default: break;
-        }
-    }
-    if (D == 16 && L == 7) return fused == 2 ? launch_group<GWide16, 7, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide16, 7, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide16, 7, 2, 0>(GROUP_ARGS);
-    if (D == 16 && L == 6) return fused == 2 ? launch_group<GWide16, 6, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide16, 6, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide16, 6, 2, 0>(GROUP_ARGS);
-    if (D == 32 && L == 7) return fused == 2 ? launch_group<GWide32, 7, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide32, 7, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide32, 7, 2, 0>(GROUP_ARGS);
-    if (D == 32 && L == 6) return fused == 2 ? launch_group<GWide32, 6, 2, 2, 1, true>(GROUP_ARGS) : fused ? launch_group<GWide32, 6, 2, 1, 1, true>(GROUP_ARGS) : launch_group<GWide32, 6, 2, 0>(GROUP_ARGS);
+    // 6 / 7 cameras: the software-pipelined kernel (msda_group2_kernel.h) for every entry -- fused (raw offsets / logits, one
+    // or P reference points per (query, level)) and the public contract (final locations / weights)
+#define G2(CFG, LL) (fused == 2 ? launch_group2<CFG, LL, 2, GROUP2_DEPTH>(GROUP_ARGS) : fused ? launch_group2<CFG, LL, 1, GROUP2_DEPTH>(GROUP_ARGS) \
+                                                                                           : launch_group2<CFG, LL, 0, GROUP2_DEPTH>(GROUP_ARGS))
+    if (D == 16 && L == 7) return G2(GWide16, 7);
+    if (D == 16 && L == 6) return G2(GWide16, 6);
+    if (D == 32 && L == 7) return G2(GWide32, 7);
+    if (D == 32 && L == 6) return G2(GWide32, 6);
+#undef G2
     return (int)hipErrorInvalidValue;
 }
 

@@ -17,13 +17,6 @@
 // kernel options (the `opts` argument)
 #define GROUP_OPT_NO_SHIFT 1      // keep the windows centred on the tile (A/B knob MVDETR_MSDA_WINDOW_SHIFT=0)
 #define GROUP_OPT_BLOCKS 2        // XCD k takes a 2-D block of the tile grid instead of a band of the job list
-// compile-time variants (the VAR template argument)
-#define VAR_LAZY_SOFTMAX 1        // online softmax rescales only when the running maximum moves by more than 8
-#define VAR_NEXT_LEVEL 2          // the next level's first camera is requested before the barriers / window copy
-#define VAR_BATCH8 8              // scheduler told to issue a half tap's 8 LDS reads before its 16 FMAs
-#define VAR_BATCH4 16             // ... 4 reads, 8 FMAs, twice
-#define VAR_EARLY 4               // first job: shape check and first sampling loads behind the shift sample's loads
-
 // -DMVDETR_GROUP_TRACE builds (libmvdetr_ops_trace.so, tools/experiments/group_trace.py): every wave's lane 0 stamps the
 // 100 MHz wall clock at the phase boundaries of its workgroup's FIRST job into a global table
 // [workgroup][wave 0..3][GROUP_TRACE_SLOTS]: 0 kernel entry, 1 shift known, 2 + 2l level l's window resident, 3 + 2l its
@@ -64,7 +57,7 @@ template <> struct MissMask<true> { using type = unsigned long long; };
 // SPLIT > 1: the workgroup has SPLIT lane groups of TH*TW*2 lanes each; all use the same staged window, group g
 // takes the cameras [g*NGA, (g+1)*NGA) with NGA = ceil(NG/SPLIT) -- NGA accumulator sets per lane instead of NG,
 // which is what makes many-camera rigs (16 cameras: 4 groups x 4) fit the register file at all.
-template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1, bool DMA = false, int VAR = 0>
+template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1, bool DMA = false>
 __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
@@ -101,10 +94,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                                             QueryLevels{0, L, S}, B, S, M, L, out);
 #endif
     };
-    // VAR_EARLY: the check runs behind the first job's first loads (its scalar loads and theirs are then in flight together;
-    // the addresses of those loads depend on level 0 only and are valid whatever the other levels look like)
-    bool checked = !(VAR & VAR_EARLY);
-    if (checked && !levels_equal()) {
+    if (!levels_equal()) {
         fallback();
         return;
     }
@@ -194,8 +184,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
 
         // sampling data of (camera, level): raw offsets (2 x float4), raw logits, reference points; camera c+1's loads are
-        // in flight while camera c's taps run, and (VAR_NEXT_LEVEL) the first camera's of level l+1 from level l's last
-        // camera on, across the barriers and the window copy
+        // in flight while camera c's taps run
         float4 na = make_float4(0, 0, 0, 0), nb = na, nw = na, nra = na, nrb = na;
         auto load_cam = [&](int c, int l) {
             const int64_t cq = cam_q(c);
@@ -217,7 +206,6 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
         // camera-split variants with four lane groups (3 waves per SIMD, 168 registers): no look-ahead, the other waves
         // cover the load -- the prefetch registers spilled (91 VGPRs at 16 cameras)
         constexpr bool AHEAD = SPLIT <= 2;
-        constexpr bool NEXT_LEVEL = AHEAD && (VAR & VAR_NEXT_LEVEL);
 
         // Window centre (round 3): the taps of a slice's heads are not centred on the query cell -- MSDeformAttn's offset
         // bias is a ray per head (ms_deform_attn.py:64-69: 1..4 px along the head's direction), so with +-6 px windows around
@@ -248,15 +236,6 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     ry = FUSED == 2 ? rp[1] : 0.25f * ((rp[1] + rp[3]) + (rp[5] + rp[7]));
                 }
             }
-            // (the sample is on its way) ... the first job's shape check and the first camera's sampling data behind it
-            if (!checked) {
-                if (!levels_equal()) {
-                    fallback();
-                    return;
-                }
-                checked = true;
-            }
-            if (NEXT_LEVEL && active) load_cam(cam0, 0);
             float sx = 0.f, sy = 0.f, sn = 0.f;
             if (s_ok) {
                 float mx = 0.25f * ((a0.x + a0.z) + (b0.x + b0.z)), my = 0.25f * ((a0.y + a0.w) + (b0.y + b0.w));
@@ -356,7 +335,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
             GROUP_STAMP(2 + 2 * l);
 
             if (active) {
-                if (AHEAD && !NEXT_LEVEL) load_cam(cam0, l);
+                if (AHEAD) load_cam(cam0, l);
 #pragma unroll
                 for (int c = 0; c < NGA; ++c) {
                     if (c >= ncam) continue;                  // (wave-uniform)
@@ -364,36 +343,26 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     float4 la = na, lb = nb, wa = nw;
                     const float4 ra = nra, rb = nrb;
                     if (AHEAD && c + 1 < ncam) load_cam(cam0 + c + 1, l);
-                    else if (NEXT_LEVEL && c + 1 == ncam && l + 1 < L) load_cam(cam0, l + 1);
                     float xs[4], ys[4];
                     if constexpr (FUSED) {
                         // fold this level's logits into camera c's running softmax
                         const float mx = fmaxf(fmaxf(wa.x, wa.y), fmaxf(wa.z, wa.w));
-                        if constexpr (VAR & VAR_LAZY_SOFTMAX) {
-                            // the reference maximum moves (and the accumulators are rescaled) only when some lane's logits
-                            // exceed it by more than 8: weights stay below e^8 of the reference, exact up to rounding, and
-                            // the 16 multiplications per (camera, level) are spent once per camera instead of L times
-                            if (__builtin_amdgcn_ballot_w64(mx > smax[c] + 8.f) != 0) {
-                                const float m = fmaxf(smax[c], mx);
-                                const float sc = __expf(smax[c] - m);
-                                ssum[c] *= sc;
-                                smax[c] = m;
-                                const float2v scv = {sc, sc};
-#pragma unroll
-                                for (int i = 0; i < 2 * NV; ++i) acc[c][i] *= scv;
-                            }
-                            const float m = smax[c];
-                            wa = make_float4(__expf(wa.x - m), __expf(wa.y - m), __expf(wa.z - m), __expf(wa.w - m));
-                            ssum[c] += (wa.x + wa.y) + (wa.z + wa.w);
-                        } else {
+                        // lazy online softmax (round 4): the reference maximum moves -- and the accumulators are rescaled --
+                        // only when some lane's logits exceed it by more than 8: weights stay below e^8 of the reference,
+                        // exact up to rounding, and the 16 multiplications per (camera, level) are spent once per camera
+                        if (__builtin_amdgcn_ballot_w64(mx > smax[c] + 8.f) != 0) {
                             const float m = fmaxf(smax[c], mx);
                             const float sc = __expf(smax[c] - m);
-                            wa = make_float4(__expf(wa.x - m), __expf(wa.y - m), __expf(wa.z - m), __expf(wa.w - m));
-                            ssum[c] = ssum[c] * sc + (wa.x + wa.y) + (wa.z + wa.w);
+                            ssum[c] *= sc;
                             smax[c] = m;
                             const float2v scv = {sc, sc};
 #pragma unroll
                             for (int i = 0; i < 2 * NV; ++i) acc[c][i] *= scv;
+                        }
+                        {
+                            const float m = smax[c];
+                            wa = make_float4(__expf(wa.x - m), __expf(wa.y - m), __expf(wa.z - m), __expf(wa.w - m));
+                            ssum[c] += (wa.x + wa.y) + (wa.z + wa.w);
                         }
                         // pixel coordinates: (ref + off / size) * size - 0.5
                         xs[0] = (ra.x + la.x * iw) * fW - 0.5f; ys[0] = (ra.y + la.y * ih) * fH - 0.5f;
@@ -417,37 +386,6 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                             const float ay1 = wy1 * a, ay0 = a - ay1;
                             const float w01 = ay0 * wx1, w00 = ay0 - w01, w11 = ay1 * wx1, w10 = ay1 - w11;
                             const float *p00 = win + __mul24(iy * WW + ix, SLICE) + lane_off;
-                            if constexpr (VAR & (VAR_BATCH8 | VAR_BATCH4)) {
-                                // Under register pressure hipcc issues the LDS reads two at a time, each pair behind a wait
-                                // (eight round trips per tap).  An empty asm that takes a batch of results as operands
-                                // makes the whole batch land before the first FMA: 8 (a window row's two corners) or 4 reads
-                                // in flight.
-                                constexpr int NB = (VAR & VAR_BATCH8) ? NV : NV / 2;
-#pragma unroll
-                                for (int r = 0; r < 2; ++r) {
-                                    const float wl = r ? w10 : w00, wr = r ? w11 : w01;
-#pragma unroll
-                                    for (int k0 = 0; k0 < NV; k0 += NB) {
-                                        float4v cl[NB], cr[NB];
-#pragma unroll
-                                        for (int k = 0; k < NB; ++k) {
-                                            const float *pk = p00 + r * (WW * SLICE) + (((k0 + k) ^ rot) << 2);
-                                            cl[k] = *reinterpret_cast<const float4v *>(pk);
-                                            cr[k] = *reinterpret_cast<const float4v *>(pk + SLICE);
-                                        }
-                                        if constexpr (NB == 4)
-                                            asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cl[2]), "+v"(cl[3]), "+v"(cr[0]), "+v"(cr[1]), "+v"(cr[2]), "+v"(cr[3]));
-                                        else
-                                            asm volatile("" : "+v"(cl[0]), "+v"(cl[1]), "+v"(cr[0]), "+v"(cr[1]));
-#pragma unroll
-                                        for (int k = 0; k < NB; ++k) {
-                                            gfma4(acc[c][2 * (k0 + k)], acc[c][2 * (k0 + k) + 1], wl, make_float4(cl[k].x, cl[k].y, cl[k].z, cl[k].w));
-                                            gfma4(acc[c][2 * (k0 + k)], acc[c][2 * (k0 + k) + 1], wr, make_float4(cr[k].x, cr[k].y, cr[k].z, cr[k].w));
-                                        }
-                                    }
-                                    if (r == 0) __builtin_amdgcn_sched_barrier(0);
-                                }
-                            } else {
 #pragma unroll
                             for (int k = 0; k < NV; ++k) {
                                 const float *pk = p00 + ((k ^ rot) << 2);
@@ -464,7 +402,6 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                                 const float4 c11 = *reinterpret_cast<const float4 *>(pk + SLICE);
                                 gfma4(acc[c][2 * k], acc[c][2 * k + 1], w10, c10);
                                 gfma4(acc[c][2 * k], acc[c][2 * k + 1], w11, c11);
-                            }
                             }
                         } else {
                             miss[c] |= (MissT)1 << (l * P + p);
@@ -544,7 +481,7 @@ using GWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 using GQuad16 = TileCfg<16, 32, 6, 16, 6, 768>;
 using GQuad32 = TileCfg<32, 32, 6, 16, 6, 768>;
 
-template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1, bool DMA = false, int VAR = 0>
+template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1, bool DMA = false>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
                         SamplingLayout lay, int B, int S, int M, float *out, const int *local_hits, int opts)
@@ -552,20 +489,20 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
     // dynamic LDS: the larger of this kernel's window and the fallback body's
     constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
                                                                                    : TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
-    auto kernel = &msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA, VAR>;
+    auto kernel = &msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA, VAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA, VAR>, Cfg::THREADS,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>, Cfg::THREADS,
                                                          LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA, VAR>));
+    static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>));
     msda_note_forward_kernel(DMA ? (SPLIT > 1 ? "msda_fwd_group[camera-split, LDS-DMA windows]" : "msda_fwd_group[LDS-DMA windows]")
                                  : (SPLIT > 1 ? "msda_fwd_group[camera-split]" : "msda_fwd_group"), &res);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts);

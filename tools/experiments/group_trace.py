@@ -82,6 +82,51 @@ def main():
         ws = [w for w in ran if w % 8 == k]
         xcc = sorted(set(int(t[w, 0, SLOTS - 1]) >> 32 & 0xf for w in ws))
         print(f"  blockIdx%8={k}: XCC_ID {xcc}  jobs {len(ws)}  mean duration {mean(dur[w] for w in ws):.1f}  last end {max(us(t[w, 0, END]) for w in ws):.1f}")
+    # who shares a CU?  HW_ID: wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13]
+    def cu_key(w):
+        hw = int(t[w, 0, SLOTS - 1])
+        return (hw >> 32 & 0xf, hw >> 13 & 7, hw >> 12 & 1, hw >> 8 & 0xf)
+    by_cu = {}
+    for w in ran:
+        by_cu.setdefault(cu_key(w), []).append(w)
+    alone = [ws[0] for ws in by_cu.values() if len(ws) == 1]
+    paired = [w for ws in by_cu.values() if len(ws) == 2 for w in ws]
+    more = [w for ws in by_cu.values() if len(ws) > 2 for w in ws]
+    print(f"CUs with a job: {len(by_cu)}; jobs alone on their CU {len(alone)} (mean {mean(dur[w] for w in alone):.1f} us), "
+          f"two per CU {len(paired)} (mean {mean(dur[w] for w in paired):.1f} us), more {len(more)}")
+    tcols = (d["W"] + 15) // 16
+    # (jobs in the last tile column are a quarter full at 180 columns)
+    simd0 = {}
+    for w in ran:
+        s4 = tuple(int(t[w, v, SLOTS - 1]) >> 4 & 3 for v in range(4))
+        simd0.setdefault(s4, []).append(dur[w])
+    print("duration by the SIMDs of waves 0..3:", "  ".join(f"{k}:{len(v)}x{mean(v):.1f}" for k, v in sorted(simd0.items())))
+    gaps = []
+    for ws in by_cu.values():
+        if len(ws) == 2:
+            gaps.append(abs(int(t[ws[0], 0, 2 + 2 * 3]) - int(t[ws[1], 0, 2 + 2 * 3])) / 100)
+    gaps.sort()
+    if gaps:
+        print(f"phase distance of a CU's two workgroups at level 3: median {gaps[len(gaps) // 2]:.2f} us, p90 {gaps[len(gaps) * 9 // 10]:.2f} us")
+    # which of a CU's two workgroups is the slower one: the one in the higher wave slots (= dispatched second)?
+    hi_slow = lo_slow = 0
+    for ws in by_cu.values():
+        if len(ws) == 2:
+            a, b2 = ws
+            sa, sb = int(t[a, 0, SLOTS - 1]) & 0xf, int(t[b2, 0, SLOTS - 1]) & 0xf
+            ea, eb = int(t[a, 0, 0]), int(t[b2, 0, 0])
+            if sa != sb:
+                slower_is_hi = (dur[a] > dur[b2]) == (sa > sb)
+                hi_slow += slower_is_hi
+                lo_slow += not slower_is_hi
+    print(f"pairs where the workgroup in the HIGHER wave slot is the slower one: {hi_slow}, the lower: {lo_slow}")
+    later = sum(1 for ws in by_cu.values() if len(ws) == 2 and (dur[ws[0]] > dur[ws[1]]) == (int(t[ws[0], 0, 0]) > int(t[ws[1], 0, 0])))
+    print(f"pairs where the workgroup that ENTERED later is the slower one: {later} of {sum(1 for ws in by_cu.values() if len(ws) == 2)}")
+    slow = sorted(ran, key=lambda w: -dur[w])[:12]
+    print("slowest jobs (wg: duration, CU key, partner's duration):")
+    for w in slow:
+        ws = by_cu[cu_key(w)]
+        print(f"   wg{w}: {dur[w]:.1f} {cu_key(w)} partners {[round(dur[x], 1) for x in ws if x != w]}")
     # the two workgroups of a CU: how far apart are they in phase at level 3?
     cus = {}
     for w in ran:
