@@ -237,15 +237,16 @@ def write_tunableop_results(tun, path):
 
 
 def load_traffic():
-    """HBM-side bytes per MSDA-forward launch from the newest committed PMC summary, or None."""
+    """HBM-side bytes per call of the path's kernels from the newest committed PMC summary (profiles/*_traffic.json,
+    written by tools/profile_bench.sh): ({"msda_fwd": bytes, "warp_fwd": ..., "warp_bwd": ..., "msda_bwd": ...}, file)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
-        return None, None
+        return {}, None
     try:
         d = json.load(open(files[-1]))
-        return d.get("msda_fwd_bytes_per_launch"), os.path.basename(files[-1])
+        return {k[:-len("_bytes_per_launch")]: v for k, v in d.items() if k.endswith("_bytes_per_launch")}, os.path.basename(files[-1])
     except Exception:
-        return None, None
+        return {}, None
 
 
 def _median_time(fn, warmup=2, reps=3):
@@ -311,10 +312,27 @@ def cpu_baseline(model, imgs_cpu, proj_cpu, budget_s):
             "host": {"logical_cpus": logical, "physical_cores": physical}, "thread_sweep": {str(k): v for k, v in sweep.items()}}
 
 
+class PhaseClock:
+    """Wall-clock seconds of the run's phases (the JSON line's `phases_s`): where a fresh box spends its minutes."""
+
+    def __init__(self):
+        self.t0 = self.last = time.perf_counter()
+        self.phases = {}
+
+    def mark(self, name):
+        now = time.perf_counter()
+        self.phases[name] = round(self.phases.get(name, 0.0) + now - self.last, 2)
+        self.last = now
+
+    def total(self):
+        return round(time.perf_counter() - self.t0, 2)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(a))
+    clock = PhaseClock()
     from mvdetr_amd import dist as mdist
     rank, world, local_rank = mdist.init_from_env()
     if not torch.cuda.is_available():
@@ -350,6 +368,7 @@ def main():
 
     MSDA.set_forward_impl(a.msda_impl)
     timer = KernelTimer(MSDA)      # callers look the functions up on the module at call time
+    clock.mark("import_and_init")
 
     geom = geometry.GEOMETRIES[a.config]
     model = build_model(a.config, seed=0, arch=a.arch)
@@ -404,11 +423,17 @@ def main():
             except Exception as ex:                # pragma: no cover
                 tuning_shared = False
                 print(f"[bench] rank {rank}: reading the shared TunableOp results failed ({ex}); tuning here", file=sys.stderr)
-    for _ in range(a.warmup):
+    clock.mark("model_and_inputs")
+    for i in range(a.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            clock.mark("first_step_incl_miopen_find_and_gemm_tuning")
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    clock.mark("warmup_rest")
+    before_timed_s = clock.total()
     timer.enabled = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -418,6 +443,7 @@ def main():
         torch.distributed.barrier()
     elapsed = mdist.barrier_and_max(time.perf_counter() - t0, dev)
     timer.enabled = False
+    clock.mark("timed_steps")
     k_us, k_n, k_bytes = timer.average_us()
     impl = MSDA.last_forward_kernel()
     fwd_resources = MSDA.last_forward_resources()          # registers / scratch (spill) bytes per lane / static LDS of that instantiation
@@ -476,11 +502,13 @@ def main():
                 at.attention_weights.weight.copy_(aw)
                 at.cache_fused_projection(True)
 
+    clock.mark("hot_path_and_init_weight_runs")
     if rank != 0:
         return
     alg_bytes = int(k_bytes) if k_bytes else None          # of the launches actually timed (rank 0's)
     full_frame = a.config == "wildtrack" and Bf == 1 and not (a.parallel == "views" and world > 1)
-    traffic, traffic_src = load_traffic() if full_frame else (None, None)
+    traffic_all, traffic_src = load_traffic() if full_frame else ({}, None)
+    traffic = traffic_all.get("msda_fwd")
     achieved = alg_bytes / (k_us * 1e-6) / 1e9 if (k_us and alg_bytes) else None
     res = {
         "metric": "multiview frames/s (7-cam Wildtrack) + MSDeformAttn HBM GB/s vs roofline",
@@ -517,10 +545,19 @@ def main():
     }
     if a.parallel == "dp" and not a.no_kernel_rooflines and hasattr(model.world_feat, "encoder"):
         res.update(other_kernel_rooflines(model, geom, feat, proj, MSDA))
+        for key, tkey in (("roofline_warp", "warp_fwd"), ("roofline_warp_bwd", "warp_bwd"), ("roofline_msda_bwd", "msda_bwd")):
+            if key in res and tkey in traffic_all:           # (same source and caveats as roofline.traffic)
+                res[key]["traffic"], res[key]["traffic_source"] = traffic_all[tkey], traffic_src
+        if "roofline_warp" in res and "warp_fwd_nchw" in traffic_all:
+            res["roofline_warp"]["nchw_to_nchw"]["traffic"] = traffic_all["warp_fwd_nchw"]
+        clock.mark("other_kernel_rooflines")
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(model, imgs[:1].cpu(), model.frame_proj_mats(M[:1]), a.cpu_budget_s)
+        clock.mark("cpu_baseline")
     else:
         res["cpu_baseline"] = None
+    res["startup"] = {"seconds_before_timed_region": before_timed_s, "phases_s": clock.phases, "total_s": clock.total(),
+                      "miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE")}
     print(json.dumps(res), flush=True)
 
 

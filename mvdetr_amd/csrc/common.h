@@ -79,6 +79,15 @@ __device__ __forceinline__ Footprint<T> footprint(T h, T w, int H, int W) {
     return f;
 }
 
+// A 16-byte global load that yields zeros when `ok` is false, without a branch and without touching `p` then: the address
+// is replaced by `safe` (any readable address) and the VALUE is selected afterwards.  (`ok ? *p : zero` makes hipcc select
+// between the global pointer and a zero it puts on the stack -- a flat load and scratch in kernels that need none.)
+__device__ __forceinline__ float4 load4_or_zero(const float *p, bool ok, const float *safe)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(ok ? p : safe);
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

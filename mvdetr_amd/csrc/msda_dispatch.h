@@ -28,6 +28,8 @@ void msda_note_forward_kernel(const char *name, const KernelResources *res = nul
 int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
                       int P, float *out, const int *local_hits);
+// false when the kernel that takes the call decides per tile, inside the launch, whether to stage windows (msda_fwd_group2)
+bool msda_forward_tile_wants_probe(int S, int M, int D, int L);
 inline int msda_forward_tile(hipStream_t, const double *, const int64_t *, const int64_t *,
                              const double *, const double *, int, int, int, int, int, int, int,
                              double *, const int *)

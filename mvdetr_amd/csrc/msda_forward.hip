@@ -124,8 +124,10 @@ static int forward_entry(void *stream, const T *value, const int64_t *shapes, co
             // `auto`: a device-side probe (stream-ordered scratch int, no host sync) tells the tile kernel whether the
             // sampling locations are near the queries' cells; if not, the same launch runs the gather formulation.
             // A forced `tile` skips the probe (the kernel is then measured as it is).
+            // (6 / 7 equal levels: msda_fwd_group2 looks at every tile's own taps and stands down job by job -- no probe
+            // kernel, no scratch allocation in front of the forward)
             int *hits = nullptr;
-            if (msda_fwd_impl_knob() == 0 &&
+            if (msda_fwd_impl_knob() == 0 && msda_forward_tile_wants_probe(S, M, D, L) &&
                 hipMallocAsync(reinterpret_cast<void **>(&hits), MSDA_PROBE_INTS * sizeof(int), st) != hipSuccess)
                 hits = nullptr;
             int rc = hits ? msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits) : 0;

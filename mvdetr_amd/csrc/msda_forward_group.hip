@@ -46,9 +46,9 @@ constexpr int GROUP2_DEPTH = 2;
 
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
-                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits)
+                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits, bool standdown)
 {
-    const int opts = group_opts(fused);
+    const int opts = group_opts(fused) | ((standdown && !fused) ? GROUP_OPT_STANDDOWN : 0);
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts
     if (L >= 9 && L <= 16)             // many cameras: 4 lane groups x up to 4 cameras (msda_forward_group_many.hip)
         return msda_forward_group_many(st, value, shapes, lsi, off, logit, ref, ref_bstride, fused, lay, B, S, M, D, L, out,

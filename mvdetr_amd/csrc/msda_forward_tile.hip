@@ -110,6 +110,16 @@ static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shap
     return (int)hipErrorInvalidValue;
 }
 
+static bool group2_takes(int S, int M, int D, int L, const SamplingLayout &lay)
+{
+    return msda_group_supported(D, L) && L <= 7 && msda_group_fits(S, M * D, lay) && !narrow_slices();
+}
+
+bool msda_forward_tile_wants_probe(int S, int M, int D, int L)
+{
+    return !group2_takes(S, M, D, L, plain_layout(M * L * TILE_P * 2, L * TILE_P * 2, TILE_P * 2, M * L * TILE_P, L * TILE_P, TILE_P));
+}
+
 int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
                       int P, float *out, const int *local_hits)
@@ -118,7 +128,8 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
     if (msda_group_supported(D, L) && msda_group_fits(S, M * D, lay) && !narrow_slices())
-        return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits);
+        return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits,
+                                  /*standdown=*/msda_fwd_impl_knob() == 0);
     return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out, local_hits);
 }
 

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
             const int sl = tid & 63, s_sub = sl & 1, s_qi = sl >> 1;
             const int s_qy = Y0 + s_qi / TW, s_qx = X0 + s_qi % TW;
             const int s_head = (hs * SLICE + s_sub * LCH) / D;
-            float sx = 0.f, sy = 0.f, sn = 0.f;
+            float sx = 0.f, sy = 0.f, sn = 0.f, sloc = 0.f;
             if (s_qy < Hq && s_qx < Wq) {
                 const int64_t s_cell = (int64_t)s_qy * Wq + s_qx, cq = cam_q(0);
                 const float *lp = off + (cq + s_cell) * lay.q_l + lay.head_l(s_head);
@@ -204,16 +204,68 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
                 } else {
                     mx = mx * fW - 0.5f - (float)s_qx;
                     my = my * fH - 0.5f - (float)s_qy;
+                    // how many of this lane's four taps lie within MSDA_PROBE_RADIUS pixels of its own cell (the stand-down
+                    // test below; the comparison is false for NaN)
+                    const float ox_ = (float)s_qx + 0.5f, oy_ = (float)s_qy + 0.5f, rr = MSDA_PROBE_RADIUS;
+                    sloc = (float)((fabsf(a0.x * fW - ox_) < rr && fabsf(a0.y * fH - oy_) < rr) + (fabsf(a0.z * fW - ox_) < rr && fabsf(a0.w * fH - oy_) < rr) +
+                                   (fabsf(b0.x * fW - ox_) < rr && fabsf(b0.y * fH - oy_) < rr) + (fabsf(b0.z * fW - ox_) < rr && fabsf(b0.w * fH - oy_) < rr));
                 }
                 if (mx == mx && my == my && fabsf(mx) < 64.f && fabsf(my) < 64.f) { sx = mx; sy = my; sn = 1.f; }
             }
-            if (active) load_cam(0, 0);
+            float scnt = (s_qy < Hq && s_qx < Wq) ? 4.f : 0.f;                 // taps sampled by this lane
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 sx += __shfl_xor(sx, o, 64);
                 sy += __shfl_xor(sy, o, 64);
                 sn += __shfl_xor(sn, o, 64);
+                if constexpr (FUSED == 0) {
+                    sloc += __shfl_xor(sloc, o, 64);
+                    scnt += __shfl_xor(scnt, o, 64);
+                }
             }
+            if constexpr (FUSED == 0) {
+                // Public contract, `auto`: the sample also says whether this tile's taps are near their cells at all.  If
+                // fewer than half are, windows would be wasted on it: the job computes its outputs in the gather formulation
+                // instead (every wave sees the same sample and takes the same way; this replaces round 3's separate probe
+                // kernel, its scratch allocation and two launch gaps in front of every forward).
+                const float tl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sloc)));
+                const float tc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scnt)));
+                if ((opts & GROUP_OPT_STANDDOWN) && tl * 2.f < tc) {
+                    // items of the job: (camera, cell of the tile, 16-byte chunk of the slice)
+                    constexpr int CH = SLICE / 4;
+                    for (int it = tid; it < NG * TH * TW * CH; it += Cfg::THREADS) {
+                        const int ck = it % CH, ci = (it / CH) % (TH * TW), c = it / (CH * TH * TW);
+                        const int gy_ = Y0 + ci / TW, gx_ = X0 + ci % TW;
+                        if (gy_ >= Hq || gx_ >= Wq) continue;
+                        const int chn = hs * SLICE + ck * 4, hd = chn / D;
+                        const int64_t q = cam_q(c) + (int64_t)gy_ * Wq + gx_;
+                        const float *lp = off + q * lay.q_l + lay.head_l(hd), *wp = logit + q * lay.q_w + lay.head_w(hd);
+                        const float *vb = value + (int64_t)b * S * row + chn;
+                        float4 r = make_float4(0, 0, 0, 0);
+                        for (int l = 0; l < L; ++l) {
+                            const float *plane = vb + lsi[l] * row;
+#pragma unroll
+                            for (int p = 0; p < P; ++p) {
+                                const float x = lp[l * lay.l_l + p * 2] * fW - 0.5f, y = lp[l * lay.l_l + p * 2 + 1] * fH - 0.5f;
+                                const float a = wp[l * lay.l_w + p];
+                                if (!(y > -1.f && x > -1.f && y < fH && x < fW)) continue;
+                                const Footprint<float> f = footprint(y, x, Hq, Wq);
+                                const float *r0 = plane + ((int64_t)f.y0 * Wq + f.x0) * row, *r1 = r0 + (int64_t)Wq * row;
+                                const float4 c00 = load4_or_zero(r0, f.vy0 && f.vx0, vb), c01 = load4_or_zero(r0 + row, f.vy0 && f.vx1, vb);
+                                const float4 c10 = load4_or_zero(r1, f.vy1 && f.vx0, vb), c11 = load4_or_zero(r1 + row, f.vy1 && f.vx1, vb);
+                                const float w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a, w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
+                                r.x += w00 * c00.x + w01 * c01.x + w10 * c10.x + w11 * c11.x;
+                                r.y += w00 * c00.y + w01 * c01.y + w10 * c10.y + w11 * c11.y;
+                                r.z += w00 * c00.z + w01 * c01.z + w10 * c10.z + w11 * c11.z;
+                                r.w += w00 * c00.w + w01 * c01.w + w10 * c10.w + w11 * c11.w;
+                            }
+                        }
+                        *reinterpret_cast<float4 *>(out + q * row + chn) = r;
+                    }
+                    continue;
+                }
+            }
+            if (active) load_cam(0, 0);
             const float tx_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
             const float ty_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy)));
             const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
@@ -403,11 +455,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
 #pragma unroll
                         for (int k = 0; k < NV; ++k) {
                             const int ko = (k ^ rot) << 2;
-                            float4 c00 = make_float4(0, 0, 0, 0), c01 = c00, c10 = c00, c11 = c00;
-                            if (f.vy0 && f.vx0) c00 = *reinterpret_cast<const float4 *>(r0 + ko);
-                            if (f.vy0 && f.vx1) c01 = *reinterpret_cast<const float4 *>(r0 + row + ko);
-                            if (f.vy1 && f.vx0) c10 = *reinterpret_cast<const float4 *>(r1 + ko);
-                            if (f.vy1 && f.vx1) c11 = *reinterpret_cast<const float4 *>(r1 + row + ko);
+                            const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch);
+                            const float4 c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
+                            const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch);
+                            const float4 c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
                             gfma4(acc[c][2 * k], acc[c][2 * k + 1], w00, c00);
                             gfma4(acc[c][2 * k], acc[c][2 * k + 1], w01, c01);
                             gfma4(acc[c][2 * k], acc[c][2 * k + 1], w10, c10);

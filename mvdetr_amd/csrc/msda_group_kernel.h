@@ -17,6 +17,7 @@
 // kernel options (the `opts` argument)
 #define GROUP_OPT_NO_SHIFT 1      // keep the windows centred on the tile (A/B knob MVDETR_MSDA_WINDOW_SHIFT=0)
 #define GROUP_OPT_BLOCKS 2        // XCD k takes a 2-D block of the tile grid instead of a band of the job list
+#define GROUP_OPT_STANDDOWN 4     // (msda_fwd_group2, public contract) a job whose taps are far from its cells gathers instead
 // -DMVDETR_GROUP_TRACE builds (libmvdetr_ops_trace.so, tools/experiments/group_trace.py): every wave's lane 0 stamps the
 // 100 MHz wall clock at the phase boundaries of its workgroup's FIRST job into a global table
 // [workgroup][wave 0..3][GROUP_TRACE_SLOTS]: 0 kernel entry, 1 shift known, 2 + 2l level l's window resident, 3 + 2l its
@@ -444,13 +445,10 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
 #pragma unroll
                     for (int k = 0; k < NV; ++k) {
                         const int ko = (k ^ rot) << 2;
-                        // (written as guarded loads: `cond ? *p : zero` became a flat load through a select between the
-                        // global pointer and a zero on the stack -- scratch in a kernel that otherwise needs none)
-                        float4 c00 = make_float4(0, 0, 0, 0), c01 = c00, c10 = c00, c11 = c00;
-                        if (f.vy0 && f.vx0) c00 = *reinterpret_cast<const float4 *>(r0 + ko);
-                        if (f.vy0 && f.vx1) c01 = *reinterpret_cast<const float4 *>(r0 + row + ko);
-                        if (f.vy1 && f.vx0) c10 = *reinterpret_cast<const float4 *>(r1 + ko);
-                        if (f.vy1 && f.vx1) c11 = *reinterpret_cast<const float4 *>(r1 + row + ko);
+                        const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch);
+                        const float4 c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
+                        const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch);
+                        const float4 c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
                         gfma4(acc[c][2 * k], acc[c][2 * k + 1], w00, c00);
                         gfma4(acc[c][2 * k], acc[c][2 * k + 1], w01, c01);
                         gfma4(acc[c][2 * k], acc[c][2 * k + 1], w10, c10);

@@ -381,11 +381,10 @@ __device__ __forceinline__ void msda_fwd_tile_body(float *win,
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     const int ko = (k ^ rot) << 2;
-                    const float4 z = make_float4(0, 0, 0, 0);
-                    const float4 c00 = (f.vy0 && f.vx0) ? *reinterpret_cast<const float4 *>(r0 + ko) : z;
-                    const float4 c01 = (f.vy0 && f.vx1) ? *reinterpret_cast<const float4 *>(r0 + row + ko) : z;
-                    const float4 c10 = (f.vy1 && f.vx0) ? *reinterpret_cast<const float4 *>(r1 + ko) : z;
-                    const float4 c11 = (f.vy1 && f.vx1) ? *reinterpret_cast<const float4 *>(r1 + row + ko) : z;
+                    const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch);
+                    const float4 c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
+                    const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch);
+                    const float4 c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
                     fma4(acc[2 * k], acc[2 * k + 1], w00, c00);
                     fma4(acc[2 * k], acc[2 * k + 1], w01, c01);
                     fma4(acc[2 * k], acc[2 * k + 1], w10, c10);

@@ -205,12 +205,14 @@ class ViewShardedFrame:
         else:
             dev = next(m.parameters()).device
             local = torch.zeros(B, 0, wf.hidden_dim, device=dev)
+        if e == s:                                         # idle rank: learn the token grid from the model
+            h, w = wf.pos_embedding.shape[-2:]
         if self.sharded is not None:
-            if e == s:                                     # idle rank: learn the token grid from the model
-                h, w = wf.pos_embedding.shape[-2:]
             fused = self.sharded(local, B, h, w)
         else:
-            tokens = all_gather_view_tokens(local, m.num_cam, self.group)
+            # (tokens per view passed explicitly: an idle rank -- 7 views over 8 GPUs -- would otherwise make every rank
+            # agree on it through an extra all-reduce and a host read-back per frame)
+            tokens = all_gather_view_tokens(local, m.num_cam, self.group, hw=h * w)
             fused = wf.fuse(tokens, B, h, w)
         return m.world_heatmap(fused), m.world_offset(fused)
 

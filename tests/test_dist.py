@@ -227,9 +227,30 @@ def _frame_worker(rank, world, port, num_views, q):
                 runner = mdist.ViewShardedFrame(model, encoder=encoder)
                 s, e = runner.range
                 assert (s, e) == mdist.partition_views(num_views, world)[rank]
-                got = runner(imgs[:, s:e], M)
+                # count the collectives of one frame: replicated = ONE token all-gather and nothing else (no all-reduce to
+                # agree on the token grid, also with an idle rank); sharded = one value all-gather per encoder layer + the
+                # all-reduce of the merge convolution's partial sums
+                calls = {"all_reduce": 0, "all_gather_into_tensor": 0}
+                real = {k: getattr(dist, k) for k in calls}
+
+                def counted(name):
+                    def f(*a, **kw):
+                        calls[name] += 1
+                        return real[name](*a, **kw)
+                    return f
+                for k in calls:
+                    setattr(dist, k, counted(k))
+                try:
+                    got = runner(imgs[:, s:e], M)
+                finally:
+                    for k in calls:
+                        setattr(dist, k, real[k])
+                n_layers = len(model.world_feat.encoder.layers)
+                want_calls = {"all_reduce": 0, "all_gather_into_tensor": 1} if encoder == "replicated" else \
+                             {"all_reduce": 1, "all_gather_into_tensor": n_layers}
+                assert calls == want_calls, (encoder, calls, want_calls)
                 err = max((got[0] - want[0]).abs().max().item(), (got[1] - want[1]).abs().max().item())
-                msgs.append(f"{encoder} {err:.2e}")
+                msgs.append(f"{encoder} {err:.2e} {calls}")
                 assert err < 5e-5, msgs
         q.put((rank, True, "; ".join(msgs)))
     except Exception:  # pragma: no cover

@@ -3,7 +3,7 @@
 # gpurun_out/profile_<tag>/ (copy them into profiles/ afterwards):
 #   <tag>_kernel_stats.txt    per-kernel calls / avg / min / max us            (--kernel-trace --stats)
 #   <tag>_pmc_*.txt           per-kernel PMC averages, one pass per counter group (--pmc only)
-#   <tag>_traffic.json        HBM-side bytes per MSDA-forward launch: (2*FETCH_SIZE + WRITE_SIZE)*1024
+#   <tag>_traffic.json        HBM-side bytes per call of every kernel group bench.py quotes: (2*FETCH_SIZE + WRITE_SIZE)*1024
 # usage: bash tools/profile_bench.sh r01 [bench args...]
 TAG=${1:-r01}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -27,13 +27,20 @@ def avg(db, counter, kern):
     v = [r[0] for r in cur.execute("select value from counters_collection where counter_name=? and kernel_name like ?", (counter, f"%{kern}%"))]
     return sum(v) / len(v) if v else None
 out = {}
-for kern, key in (("msda_fwd", "msda_fwd"), ("warp_fwd", "warp_fwd")):
-    f = avg("$O/pmc_fetch/p_results.db", "FETCH_SIZE", kern)
-    w = avg("$O/pmc_write/p_results.db", "WRITE_SIZE", kern)
-    if f is not None and w is not None:
-        out[key + "_fetch_size_kb_raw"] = f
-        out[key + "_write_size_kb"] = w
-        out[key + "_bytes_per_launch"] = int((2 * f + w) * 1024)
+# bench.py key -> the kernels of one call (per-launch averages are summed: a call launches each of them once)
+groups = {"msda_fwd": ["msda_fwd_group"], "warp_fwd": ["warp_fwd_cl<"], "warp_fwd_nchw": ["warp_fwd<"],
+          "warp_bwd": ["warp_bwd_scans", "warp_bwd_gather"],
+          "msda_bwd": ["msda_bwd_value_win", "msda_bwd_sampling", "msda_locality_probe", "msda_bwd_fused"]}
+for key, kerns in groups.items():
+    f = [avg("$O/pmc_fetch/p_results.db", "FETCH_SIZE", k) for k in kerns]
+    w = [avg("$O/pmc_write/p_results.db", "WRITE_SIZE", k) for k in kerns]
+    f = [x for x in f if x is not None]
+    w = [x for x in w if x is not None]
+    if f and w:
+        out[key + "_fetch_size_kb_raw"] = sum(f)
+        out[key + "_write_size_kb"] = sum(w)
+        out[key + "_bytes_per_launch"] = int((2 * sum(f) + sum(w)) * 1024)
+        out[key + "_kernels"] = kerns
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over: python bench.py $ARGS; "
                "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane "
                "reads (MI355X_MICROARCH.md, HBM section; re-checked here on a device copy of known size), WRITE_SIZE is exact. "
