@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 9
+#define MVDETR_OPS_ABI_VERSION 10
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -175,6 +175,30 @@ int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, co
 int mvdetr_warp_perspective_backward_f64(void *stream, const double *grad_dst, const double *M,
                                          int n, int channels, int src_h, int src_w, int dst_h,
                                          int dst_w, int layout_nhwc, double *grad_src);
+
+/* The same gradient in two steps, for callers whose matrices stay the same from call to call (training without
+ * augmentation: the projection matrices are constants, mvdetr.py:82-95,155-161).  The gather's geometry -- which destination
+ * pixels can touch each 2x2 block of source texels -- depends on M and the shapes only:
+ *   mvdetr_warp_backward_plan_bytes   size of the plan of such a call in bytes, 0 when the gather does not take the shapes
+ *                                     (channels * elem_size not a multiple of 16, more than 2^31 elements, or
+ *                                     MVDETR_WARP_BWD_IMPL=scatter): use mvdetr_warp_perspective_backward_* then
+ *   mvdetr_warp_backward_plan_*       fills `plan` (caller-owned device memory of that size, 16-byte aligned) for M [n,3,3]
+ *   mvdetr_warp_perspective_backward_planned_*   the gradient from a plan built for the same M and shapes; the plan is only
+ *                                     read (any number of calls, any streams ordered after the plan's); layouts: channel-last
+ *                                     on both sides (layout_nhwc bits 0 and 1 set; bit 2 = nearest), 16-byte aligned tensors
+ * One kernel per call instead of two and a stream write, no library-side scratch.  Results are bit-identical to
+ * mvdetr_warp_perspective_backward_* (the same kernels). */
+int64_t mvdetr_warp_backward_plan_bytes(int n, int channels, int src_h, int src_w, int dst_h, int dst_w, int elem_size);
+int mvdetr_warp_backward_plan_f32(void *stream, const float *M, int n, int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                  void *plan);
+int mvdetr_warp_backward_plan_f64(void *stream, const double *M, int n, int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                  void *plan);
+int mvdetr_warp_perspective_backward_planned_f32(void *stream, const float *grad_dst, const float *M, const void *plan, int n,
+                                                 int channels, int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                 float *grad_src);
+int mvdetr_warp_perspective_backward_planned_f64(void *stream, const double *grad_dst, const double *M, const void *plan, int n,
+                                                 int channels, int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                 double *grad_src);
 
 /* ---- Residual add + LayerNorm (the tail of both halves of the shadow transformer's encoder layer) -------
  * Replaces  self.norm1(src + self.dropout1(src2))  /  self.norm2(src + self.dropout3(ffn))  in eval mode

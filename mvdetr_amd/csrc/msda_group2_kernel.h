@@ -231,36 +231,54 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
                 const float tl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sloc)));
                 const float tc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scnt)));
                 if ((opts & GROUP_OPT_STANDDOWN) && tl * 2.f < tc) {
-                    // items of the job: (camera, cell of the tile, 16-byte chunk of the slice)
-                    constexpr int CH = SLICE / 4;
-                    for (int it = tid; it < NG * TH * TW * CH; it += Cfg::THREADS) {
-                        const int ck = it % CH, ci = (it / CH) % (TH * TW), c = it / (CH * TH * TW);
-                        const int gy_ = Y0 + ci / TW, gx_ = X0 + ci % TW;
-                        if (gy_ >= Hq || gx_ >= Wq) continue;
-                        const int chn = hs * SLICE + ck * 4, hd = chn / D;
-                        const int64_t q = cam_q(c) + (int64_t)gy_ * Wq + gx_;
-                        const float *lp = off + q * lay.q_l + lay.head_l(hd), *wp = logit + q * lay.q_w + lay.head_w(hd);
-                        const float *vb = value + (int64_t)b * S * row + chn;
-                        float4 r = make_float4(0, 0, 0, 0);
+                    // items of the job: (camera, cell of the tile, 16-byte chunk of the slice); GU per lane and iteration,
+                    // branch-free, so that their loads are in flight together
+                    constexpr int CH = SLICE / 4, NIT = NG * TH * TW * CH, T = Cfg::THREADS, GU = 4;
+                    for (int it0 = tid; it0 < NIT; it0 += GU * T) {
+                        const float *lp[GU], *wp[GU], *vb[GU];
+                        float *op[GU];
+                        bool live[GU];
+                        float4 r[GU];
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) {
+                            const int it = it0 + u * T;
+                            const int ck = it % CH, ci = (it / CH) % (TH * TW), c = min(it / (CH * TH * TW), NG - 1);
+                            const int gy_ = Y0 + ci / TW, gx_ = X0 + ci % TW;
+                            live[u] = it < NIT && gy_ < Hq && gx_ < Wq;
+                            const int chn = hs * SLICE + ck * 4, hd = chn / D;
+                            const int64_t q = cam_q(c) + (live[u] ? (int64_t)gy_ * Wq + gx_ : 0);
+                            lp[u] = off + q * lay.q_l + lay.head_l(hd);
+                            wp[u] = logit + q * lay.q_w + lay.head_w(hd);
+                            vb[u] = value + (int64_t)b * S * row + chn;
+                            op[u] = out + q * row + chn;
+                            r[u] = make_float4(0, 0, 0, 0);
+                        }
                         for (int l = 0; l < L; ++l) {
-                            const float *plane = vb + lsi[l] * row;
 #pragma unroll
                             for (int p = 0; p < P; ++p) {
-                                const float x = lp[l * lay.l_l + p * 2] * fW - 0.5f, y = lp[l * lay.l_l + p * 2 + 1] * fH - 0.5f;
-                                const float a = wp[l * lay.l_w + p];
-                                if (!(y > -1.f && x > -1.f && y < fH && x < fW)) continue;
-                                const Footprint<float> f = footprint(y, x, Hq, Wq);
-                                const float *r0 = plane + ((int64_t)f.y0 * Wq + f.x0) * row, *r1 = r0 + (int64_t)Wq * row;
-                                const float4 c00 = load4_or_zero(r0, f.vy0 && f.vx0, vb), c01 = load4_or_zero(r0 + row, f.vy0 && f.vx1, vb);
-                                const float4 c10 = load4_or_zero(r1, f.vy1 && f.vx0, vb), c11 = load4_or_zero(r1 + row, f.vy1 && f.vx1, vb);
-                                const float w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a, w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
-                                r.x += w00 * c00.x + w01 * c01.x + w10 * c10.x + w11 * c11.x;
-                                r.y += w00 * c00.y + w01 * c01.y + w10 * c10.y + w11 * c11.y;
-                                r.z += w00 * c00.z + w01 * c01.z + w10 * c10.z + w11 * c11.z;
-                                r.w += w00 * c00.w + w01 * c01.w + w10 * c10.w + w11 * c11.w;
+#pragma unroll
+                                for (int u = 0; u < GU; ++u) {
+                                    float x = lp[u][l * lay.l_l + p * 2] * fW - 0.5f, y = lp[u][l * lay.l_l + p * 2 + 1] * fH - 0.5f;
+                                    float a = wp[u][l * lay.l_w + p];
+                                    const bool ok = y > -1.f && x > -1.f && y < fH && x < fW;      // (false for NaN)
+                                    x = ok ? x : 0.f;
+                                    y = ok ? y : 0.f;
+                                    a = ok ? a : 0.f;
+                                    const Footprint<float> f = footprint(y, x, Hq, Wq);
+                                    const float *r0 = vb[u] + lsi[l] * row + ((int64_t)f.y0 * Wq + f.x0) * row, *r1 = r0 + (int64_t)Wq * row;
+                                    const float4 c00 = load4_or_zero(r0, f.vy0 && f.vx0, vb[u]), c01 = load4_or_zero(r0 + row, f.vy0 && f.vx1, vb[u]);
+                                    const float4 c10 = load4_or_zero(r1, f.vy1 && f.vx0, vb[u]), c11 = load4_or_zero(r1 + row, f.vy1 && f.vx1, vb[u]);
+                                    const float w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a, w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
+                                    r[u].x += w00 * c00.x + w01 * c01.x + w10 * c10.x + w11 * c11.x;
+                                    r[u].y += w00 * c00.y + w01 * c01.y + w10 * c10.y + w11 * c11.y;
+                                    r[u].z += w00 * c00.z + w01 * c01.z + w10 * c10.z + w11 * c11.z;
+                                    r[u].w += w00 * c00.w + w01 * c01.w + w10 * c10.w + w11 * c11.w;
+                                }
                             }
                         }
-                        *reinterpret_cast<float4 *>(out + q * row + chn) = r;
+#pragma unroll
+                        for (int u = 0; u < GU; ++u)
+                            if (live[u]) *reinterpret_cast<float4 *>(op[u]) = r[u];
                     }
                     continue;
                 }

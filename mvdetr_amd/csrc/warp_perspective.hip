@@ -633,7 +633,10 @@ __global__ __launch_bounds__(WARP_SCAN_THREADS) void warp_bwd_scans(const T *__r
             if (u0 <= u1) {
                 const double len = floor(vb - va + 2.0 * MARGIN) + 2.0;
                 cost = (u1 - u0 + 1.0) * len;
-                if (!(cost < 2.0e9)) continue;
+                // (a square just below the horizon has a far-end image 1e5 .. 1e7 pixels long: the lines are clamped to the
+                // grid but their length is not, so such a scan walks millions of candidates outside the grid.  The clipping
+                // path below never costs more than H * W candidates: anything dearer than that is left to it.)
+                if (!(cost <= (double)H * (double)W)) continue;
                 z.u0 = (int)u0; z.u1 = (int)u1; z.len = (int)len; z.swap = swap; z.a = va - MARGIN; z.s = sh; z.uc = uc;
             }
             if (cost < best) { best = cost; b0 = z; }
@@ -963,51 +966,103 @@ static char *warp_stream_scratch(hipStream_t st, size_t bytes, hipError_t &rc)
     return e.ptr;
 }
 
-template <typename T>
-static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv, int N, int C, int h, int w, int H,
-                                  int W, int nearest, T *grad_src)
+// Layout of the gather backward's geometry ("plan"): [counts: heavy, odd, odd per segment | scans: 2 per 2 x 2 block | heavy-
+// block list | odd-pixel list].  It depends on the matrices and the shapes only, not on the gradient.
+struct WarpPlanLayout {
+    size_t count_bytes, scan_bytes, heavy_bytes, odd_bytes;
+    int64_t nblk, npix;
+    size_t total() const { return count_bytes + scan_bytes + heavy_bytes + odd_bytes; }
+};
+static WarpPlanLayout warp_plan_layout(int N, int h, int w, int H, int W)
+{
+    WarpPlanLayout L;
+    L.nblk = (int64_t)N * ((h + 1) / 2) * ((w + 1) / 2);
+    L.npix = (int64_t)N * H * W;
+    L.count_bytes = ((2 + WARP_ODD_SEGS) * sizeof(int) + 15) / 16 * 16;
+    L.scan_bytes = (size_t)L.nblk * 2 * sizeof(WarpScan);
+    L.heavy_bytes = ((size_t)L.nblk * sizeof(int) + 15) / 16 * 16;
+    const int64_t odd_per = (L.npix + WARP_ODD_SEGS - 1) / WARP_ODD_SEGS;
+    L.odd_bytes = (size_t)odd_per * WARP_ODD_SEGS * sizeof(int);
+    return L;
+}
+
+// does the gather take these shapes?  (lgG / cgroups: lanes per hit stream, channel groups per block)
+template <typename T> static bool warp_gather_shapes(int N, int C, int h, int w, int H, int W, int &lgG, int &cgroups, int64_t &wgs)
 {
     constexpr int VEC = 16 / (int)sizeof(T);
+    if (C <= 0 || C % VEC) return false;
     const int chunks = C / VEC;
-    int lgG = 0;
+    lgG = 0;
     while ((1 << lgG) < chunks && lgG < 6) ++lgG;
-    const int G = 1 << lgG, cgroups = (chunks + G - 1) / G;
-    const int64_t nblk = (int64_t)N * ((h + 1) / 2) * ((w + 1) / 2);
-    const int64_t wgs = (nblk * cgroups + 3) / 4;
-    const int64_t npix = (int64_t)N * H * W;
-    if (wgs > 0x7fffffffLL || npix * C > 0x7fffffffLL) return (int)hipErrorNotSupported;
+    const int G = 1 << lgG;
+    cgroups = (chunks + G - 1) / G;
+    const WarpPlanLayout L = warp_plan_layout(N, h, w, H, W);
+    wgs = (L.nblk * cgroups + 3) / 4;
+    return wgs <= 0x7fffffffLL && L.npix * C <= 0x7fffffffLL;
+}
+
+// the geometry pass: candidate scans of every block, the heavy-block list, the pixels kornia does not divide
+template <typename T>
+static int warp_bwd_plan_launch(hipStream_t st, const T *Mv, int N, int h, int w, int H, int W, char *plan)
+{
+    const WarpPlanLayout L = warp_plan_layout(N, h, w, H, W);
     const char *ge = getenv("MVDETR_WARP_BWD_GEOMETRY");
     const int force_clip = ge && !strcmp(ge, "clip");
-    // stream-ordered scratch: [counts: heavy, odd, odd per segment | scans: 2 per block | heavy-block list | odd-pixel list]
-    const size_t count_bytes = ((2 + WARP_ODD_SEGS) * sizeof(int) + 15) / 16 * 16;
-    const size_t scan_bytes = (size_t)nblk * 2 * sizeof(WarpScan), heavy_bytes = (size_t)nblk * sizeof(int);
-    const int64_t odd_per = (npix + WARP_ODD_SEGS - 1) / WARP_ODD_SEGS;
-    const size_t odd_bytes = (size_t)odd_per * WARP_ODD_SEGS * sizeof(int);
-    // (kept per stream between calls: hipMallocAsync + hipFreeAsync cost the host ~10 us per call, more than the launches)
-    hipError_t rc = hipSuccess;
-    char *scratch = warp_stream_scratch(st, count_bytes + scan_bytes + heavy_bytes + odd_bytes, rc);
-    if (!scratch) return (int)rc;
-    int *counts = reinterpret_cast<int *>(scratch);
-    WarpScan *scans = reinterpret_cast<WarpScan *>(scratch + count_bytes);
-    int *heavy_list = reinterpret_cast<int *>(scratch + count_bytes + scan_bytes);
-    int *odd_list = reinterpret_cast<int *>(scratch + count_bytes + scan_bytes + heavy_bytes);
+    int *counts = reinterpret_cast<int *>(plan);
+    WarpScan *scans = reinterpret_cast<WarpScan *>(plan + L.count_bytes);
+    int *heavy_list = reinterpret_cast<int *>(plan + L.count_bytes + L.scan_bytes);
+    int *odd_list = reinterpret_cast<int *>(plan + L.count_bytes + L.scan_bytes + L.heavy_bytes);
     // the two running counters start from zero: one 8-byte stream write (a command-processor packet, no fill kernel)
-    rc = hipStreamWriteValue64(st, counts, 0, 0);
+    hipError_t rc = hipStreamWriteValue64(st, counts, 0, 0);
     if (rc != hipSuccess) {
         (void)hipGetLastError();
         rc = hipMemsetAsync(counts, 0, 2 * sizeof(int), st);
+        if (rc != hipSuccess) return (int)rc;
     }
     const char *he = getenv("MVDETR_WARP_BWD_HEAVY");        // (test knob: 0 = every block with candidates is "heavy")
     const int heavy_above = he ? atoi(he) : WARP_HEAVY;
-    const int64_t scan_wgs = (nblk + WARP_SCAN_THREADS - 1) / WARP_SCAN_THREADS;
+    const int64_t scan_wgs = (L.nblk + WARP_SCAN_THREADS - 1) / WARP_SCAN_THREADS;
     hipLaunchKernelGGL((warp_bwd_scans<T>), dim3((unsigned)(scan_wgs + WARP_ODD_SEGS)), dim3(WARP_SCAN_THREADS), 0, st, Mv, N,
                        h, w, H, W, force_clip, heavy_above, scans, heavy_list, counts, odd_list);
+    return (int)hipGetLastError();
+}
+
+// the gradient from a plan of the same matrices and shapes (the plan is only read)
+template <typename T>
+static int warp_bwd_planned_launch(hipStream_t st, const T *grad_dst, const T *Mv, const char *plan, int N, int C, int h,
+                                   int w, int H, int W, int nearest, T *grad_src)
+{
+    int lgG, cgroups;
+    int64_t wgs;
+    if (!warp_gather_shapes<T>(N, C, h, w, H, W, lgG, cgroups, wgs)) return (int)hipErrorNotSupported;
+    const WarpPlanLayout L = warp_plan_layout(N, h, w, H, W);
+    const int *counts = reinterpret_cast<const int *>(plan);
+    const WarpScan *scans = reinterpret_cast<const WarpScan *>(plan + L.count_bytes);
+    const int *heavy_list = reinterpret_cast<const int *>(plan + L.count_bytes + L.scan_bytes);
+    const int *odd_list = reinterpret_cast<const int *>(plan + L.count_bytes + L.scan_bytes + L.heavy_bytes);
     const char *hw = getenv("MVDETR_WARP_BWD_HEAVY_WGS");
     const int heavy_wgs = hw ? (atoi(hw) > 0 ? atoi(hw) : 1) : WARP_HEAVY_WGS;
     hipLaunchKernelGGL((warp_bwd_gather<T>), dim3((unsigned)(wgs + heavy_wgs)), dim3(256), 0, st, grad_dst, Mv, scans,
                        heavy_list, counts, odd_list, N, C, h, w, H, W, nearest, lgG, cgroups, heavy_wgs, grad_src);
-    if (rc == hipSuccess) rc = hipGetLastError();
-    return (int)rc;
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv, int N, int C, int h, int w, int H,
+                                  int W, int nearest, T *grad_src)
+{
+    int lgG, cgroups;
+    int64_t wgs;
+    if (!warp_gather_shapes<T>(N, C, h, w, H, W, lgG, cgroups, wgs)) return (int)hipErrorNotSupported;
+    // the plan of this call in stream-ordered scratch (kept per stream between calls: hipMallocAsync + hipFreeAsync cost the
+    // host ~10 us per call, more than the launches); callers whose matrices do not change build it once instead
+    // (mvdetr_warp_backward_plan_*, mvdetr_warp_perspective_backward_planned_*)
+    hipError_t rc = hipSuccess;
+    char *scratch = warp_stream_scratch(st, warp_plan_layout(N, h, w, H, W).total(), rc);
+    if (!scratch) return (int)rc;
+    const int r1 = warp_bwd_plan_launch<T>(st, Mv, N, h, w, H, W, scratch);
+    if (r1) return r1;
+    return warp_bwd_planned_launch<T>(st, grad_dst, Mv, scratch, N, C, h, w, H, W, nearest, grad_src);
 }
 
 template <typename T>
@@ -1122,7 +1177,43 @@ template <typename T> static int transpose_entry(void *stream, const T *src, int
     return (int)hipGetLastError();
 }
 
+// ---- the two-step gradient (plan + planned call) behind the C ABI -----------------------------------------------------
+static int64_t plan_bytes(int n, int channels, int src_h, int src_w, int dst_h, int dst_w, int elem_size)
+{
+    if (n <= 0 || channels <= 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) return 0;
+    int lgG, cgroups;
+    int64_t wgs;
+    const bool ok = elem_size == 4   ? warp_gather_shapes<float>(n, channels, src_h, src_w, dst_h, dst_w, lgG, cgroups, wgs)
+                    : elem_size == 8 ? warp_gather_shapes<double>(n, channels, src_h, src_w, dst_h, dst_w, lgG, cgroups, wgs)
+                                     : false;
+    if (!ok || (int64_t)src_h * src_w * channels > 0x7fffffffLL || warp_bwd_impl()) return 0;
+    return (int64_t)warp_plan_layout(n, src_h, src_w, dst_h, dst_w).total();
+}
+
+template <typename T>
+static int plan_entry(void *stream, const T *M, int n, int channels, int src_h, int src_w, int dst_h, int dst_w, void *plan)
+{
+    if (!M || !plan || (reinterpret_cast<uintptr_t>(plan) & 15)) return (int)hipErrorInvalidValue;
+    if (!plan_bytes(n, channels, src_h, src_w, dst_h, dst_w, (int)sizeof(T))) return (int)hipErrorNotSupported;
+    return warp_bwd_plan_launch<T>(reinterpret_cast<hipStream_t>(stream), M, n, src_h, src_w, dst_h, dst_w,
+                                           static_cast<char *>(plan));
+}
+template <typename T>
+static int planned_entry(void *stream, const T *grad_dst, const T *M, const void *plan, int n, int channels, int src_h, int src_w,
+                         int dst_h, int dst_w, int layout_nhwc, T *grad_src)
+{
+    // channel-last on both sides (bits 0 and 1), bilinear or nearest (bit 2): the layouts the gather exists for
+    if ((layout_nhwc & ~7) || (layout_nhwc & 3) != 3 || !grad_dst || !M || !plan || !grad_src) return (int)hipErrorInvalidValue;
+    if (!plan_bytes(n, channels, src_h, src_w, dst_h, dst_w, (int)sizeof(T)) ||
+        !aligned(grad_dst, 16) || !aligned(grad_src, 16))
+        return (int)hipErrorNotSupported;
+    g_warp_last_kernel = "warp_bwd_gather[planned]";
+    return warp_bwd_planned_launch<T>(reinterpret_cast<hipStream_t>(stream), grad_dst, M, static_cast<const char *>(plan), n,
+                                              channels, src_h, src_w, dst_h, dst_w, (layout_nhwc >> 2) & 1, grad_src);
+}
+
 }  // namespace mvdetr
+
 
 extern "C" {
 
@@ -1160,6 +1251,34 @@ int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, co
 {
     return mvdetr::warp_entry<float>(true, stream, grad_dst, M, n, channels, src_h, src_w, dst_h, dst_w,
                                      layout_nhwc, grad_src);
+}
+
+int64_t mvdetr_warp_backward_plan_bytes(int n, int channels, int src_h, int src_w, int dst_h, int dst_w, int elem_size)
+{
+    return mvdetr::plan_bytes(n, channels, src_h, src_w, dst_h, dst_w, elem_size);
+}
+
+int mvdetr_warp_backward_plan_f32(void *stream, const float *M, int n, int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                  void *plan)
+{
+    return mvdetr::plan_entry<float>(stream, M, n, channels, src_h, src_w, dst_h, dst_w, plan);
+}
+int mvdetr_warp_backward_plan_f64(void *stream, const double *M, int n, int channels, int src_h, int src_w, int dst_h, int dst_w,
+                                  void *plan)
+{
+    return mvdetr::plan_entry<double>(stream, M, n, channels, src_h, src_w, dst_h, dst_w, plan);
+}
+int mvdetr_warp_perspective_backward_planned_f32(void *stream, const float *grad_dst, const float *M, const void *plan, int n,
+                                                 int channels, int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                 float *grad_src)
+{
+    return mvdetr::planned_entry<float>(stream, grad_dst, M, plan, n, channels, src_h, src_w, dst_h, dst_w, layout_nhwc, grad_src);
+}
+int mvdetr_warp_perspective_backward_planned_f64(void *stream, const double *grad_dst, const double *M, const void *plan, int n,
+                                                 int channels, int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                 double *grad_src)
+{
+    return mvdetr::planned_entry<double>(stream, grad_dst, M, plan, n, channels, src_h, src_w, dst_h, dst_w, layout_nhwc, grad_src);
 }
 
 int mvdetr_warp_perspective_backward_f64(void *stream, const double *grad_dst, const double *M,

@@ -10,6 +10,8 @@ seeded random: there is no network for the pretrained download (resnet.py:213-21
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 from torch import nn
 
@@ -105,6 +107,38 @@ def output_head(in_dim, feat_dim, out_dim):
     return nn.Sequential(nn.Conv2d(in_dim, out_dim, 1))
 
 
+class _ProjUpload:
+    """Uploads of the per-frame projection matrices for one (device, thread): a ring of three pinned staging buffers (the
+    host only waits for the upload issued three frames ago, not for the previous frame's -- which queues behind that
+    frame's kernels), and the last upload is handed out again while the matrices do not change (no augmentation: the
+    same device tensor every frame, so that consumers keyed on it -- the warp gradient's plan -- see it unchanged)."""
+    RING = 3
+
+    def __init__(self):
+        self.bufs, self.events, self.next = [], [], 0
+        self.last_host, self.last_dev = None, None
+
+    def upload(self, proj, dev):
+        if self.last_host is not None and self.last_dev is not None and self.last_dev.device == dev \
+                and self.last_host.shape == proj.shape and torch.equal(self.last_host, proj):
+            return self.last_dev
+        if not self.bufs or self.bufs[0].shape != proj.shape:
+            self.bufs = [torch.empty_like(proj).pin_memory() for _ in range(self.RING)]
+            self.events = [None] * self.RING
+            self.next = 0
+        i = self.next
+        self.next = (i + 1) % self.RING
+        if self.events[i] is not None:
+            self.events[i].synchronize()                                  # that buffer's previous upload has left it
+        self.bufs[i].copy_(proj)
+        out = self.bufs[i].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.events[i] = ev
+        self.last_host, self.last_dev = proj.clone(), out
+        return out
+
+
 class MVDeTr(nn.Module):
     def __init__(self, geom: geometry.SceneGeometry, Ks, Rts, arch="resnet18", z=0, world_feat_arch="deform_trans",
                  bottleneck_dim=None, outfeat_dim=0, dropout=0.5, channels_last=True):
@@ -118,8 +152,8 @@ class MVDeTr(nn.Module):
         self.register_buffer("proj_mats", torch.from_numpy(geometry.build_proj_mats(geom, Ks, Rts, z)), persistent=False)
         # host copy for the per-frame composition: the buffer above follows .to(device) (it is part of the reference's
         # attribute set, mvdetr.py:95), and reading it back every forward would be a full-stream sync per frame
-        self._proj_mats_host, self._proj_host_key = None, None
-        self._proj_pinned, self._proj_pinned_event = None, None
+        self._proj_mats_host, self._proj_host_src, self._proj_host_version = None, None, None
+        self._transient = {}
         if arch not in ("resnet18", "resnet50"):
             raise ValueError("trunks: resnet18 (the reference's default, mvdetr.py:102-105) or resnet50 (BASELINE configs[3]; "
                              "resnet.py:244); vgg11 is not provided")
@@ -160,22 +194,32 @@ class MVDeTr(nn.Module):
         so the host can queue frame k+1 behind frame k (the reference composes on the CPU and does a pageable
         ``.to(device)`` every forward, mvdetr.py:194)."""
         pm = self.proj_mats
-        key = (id(pm), pm._version)                                       # refreshed (one sync) after .to(device) / in-place edits
-        if key != self._proj_host_key:
-            self._proj_mats_host, self._proj_host_key = pm.detach().cpu().clone(), key
+        # (the source tensor itself is held and compared with `is`: an id() alone can be reused by a later tensor)
+        if pm is not self._proj_host_src or pm._version != self._proj_host_version:
+            self._proj_mats_host = pm.detach().cpu().clone()              # one sync, after .to(device) / in-place edits
+            self._proj_host_src, self._proj_host_version = pm, pm._version
         proj = geometry.compose_frame_proj_mats(self._proj_mats_host, M.cpu(), self.img_reduce)
         if device is None or torch.device(device).type == "cpu":
             return proj
-        if self._proj_pinned is None or self._proj_pinned.shape != proj.shape:
-            self._proj_pinned = torch.empty_like(proj).pin_memory()
-            self._proj_pinned_event = None
-        if self._proj_pinned_event is not None:
-            self._proj_pinned_event.synchronize()                         # the previous frame's upload has left the buffer
-        self._proj_pinned.copy_(proj)
-        out = self._proj_pinned.to(device, non_blocking=True)
-        self._proj_pinned_event = torch.cuda.Event()
-        self._proj_pinned_event.record(torch.cuda.current_stream(device))
-        return out
+        dev = torch.device(device)
+        t = self._transient.setdefault((dev.type, dev.index, threading.get_ident()), _ProjUpload())
+        return t.upload(proj, dev)
+
+    # the pinned staging buffers / events / cached uploads are per (device, thread) run-time state, not part of the model:
+    # they are not pickled, deep-copied or shared between DataParallel replicas' threads
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_transient"] = {}
+        d["_proj_mats_host"], d["_proj_host_src"], d["_proj_host_version"] = None, None, None
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def features(self, imgs):
         B, N, C, H, W = imgs.shape

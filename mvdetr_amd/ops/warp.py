@@ -16,7 +16,16 @@ from .. import _lib
 DST_NHWC, SRC_NHWC, NEAREST = 1, 2, 4          # bits of the C ABI's layout_nhwc argument (include/mvdetr_ops.h)
 
 
-def _launch(name, a, M, n, c, h, w, H, W, layout, out):
+def _launch(name, a, M, n, c, h, w, H, W, layout, out, plan=None):
+    """One C-ABI call: ``name`` = "forward" | "backward"; with ``plan`` (backward only) the two-step gradient's second step
+    (mvdetr_warp_perspective_backward_planned_*)."""
+    if plan is not None:
+        with torch.cuda.device(a.device):
+            rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_backward_planned_{_lib.suffix(a.dtype)}")(
+                _lib.current_stream_ptr(a.device), a.data_ptr(), M.data_ptr(), plan.data_ptr(), n, c, h, w, H, W, layout,
+                out.data_ptr())
+        _lib.check(rc, "warp_perspective_backward_planned")
+        return
     if not a.is_cuda:
         # the library's own CPU path (csrc/host_path.cpp): same layouts; the interpolation mode is its own argument
         rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_{name}_host_{_lib.suffix(a.dtype)}")(
@@ -58,6 +67,43 @@ def _channel_last_source(src, channels_last_out):
             and not src.is_contiguous() and (c * src.element_size()) % 16 == 0 and src.data_ptr() % 16 == 0)
 
 
+class _BackwardPlans:
+    """Plans of the gather backward (csrc/warp_perspective.hip: which destination pixels can touch each 2x2 block of source
+    texels) for the matrices seen lately.  A plan depends on M and the shapes only, so training without augmentation -- the
+    same projection matrices every iteration -- builds it once and every backward is ONE kernel.  Entries hold the matrix
+    tensor itself (its storage cannot be handed to another tensor while cached) and its version counter; writes through
+    ``.data`` are invisible to it, like to autograd."""
+    KEEP = 4
+
+    def __init__(self):
+        self.entries = []          # (M, version, shapes, plan), most recent first
+
+    def get(self, M, shapes):
+        n, c, h, w, H, W = shapes
+        for i, (m, ver, shp, plan) in enumerate(self.entries):
+            if shp == shapes and m.data_ptr() == M.data_ptr() and ver == M._version and m.device == M.device and m.dtype == M.dtype:
+                if i:
+                    self.entries.insert(0, self.entries.pop(i))
+                return plan
+        nbytes = int(_lib.lib().mvdetr_warp_backward_plan_bytes(n, c, h, w, H, W, M.element_size()))
+        if nbytes <= 0:
+            return None
+        plan = torch.empty(nbytes, dtype=torch.uint8, device=M.device)
+        with torch.cuda.device(M.device):
+            rc = getattr(_lib.lib(), f"mvdetr_warp_backward_plan_{_lib.suffix(M.dtype)}")(
+                _lib.current_stream_ptr(M.device), M.data_ptr(), n, c, h, w, H, W, plan.data_ptr())
+        if rc == 801:                                        # hipErrorNotSupported: the scatter kernels take the call
+            return None
+        _lib.check(rc, "warp_backward_plan")
+        # (a plan built on one stream and used on another: the caching allocator's stream semantics apply, as for any tensor)
+        self.entries.insert(0, (M, M._version, shapes, plan))
+        del self.entries[self.KEEP:]
+        return plan
+
+
+_plans = _BackwardPlans()
+
+
 class WarpPerspectiveFunction(Function):
     @staticmethod
     def forward(ctx, src, M, dsize, channels_last_out, nearest=False):
@@ -96,7 +142,11 @@ class WarpPerspectiveFunction(Function):
             g = grad_out.contiguous() if layout & DST_NHWC else _transpose(grad_out.contiguous(), n, c, H * W)
             grad_src = torch.empty((n, c, h, w), dtype=grad_out.dtype, device=grad_out.device,
                                    memory_format=torch.channels_last)
-            _launch("backward", g, M, n, c, h, w, H, W, DST_NHWC | SRC_NHWC | near, grad_src)
+            plan = _plans.get(M, (n, c, h, w, H, W)) if g.data_ptr() % 16 == 0 else None
+            if plan is not None:
+                _launch("backward", g, M, n, c, h, w, H, W, DST_NHWC | SRC_NHWC | near, grad_src, plan=plan)
+            else:
+                _launch("backward", g, M, n, c, h, w, H, W, DST_NHWC | SRC_NHWC | near, grad_src)
             if ctx.src_was_cl:
                 return grad_src, None, None, None, None
             return _transpose(grad_src.permute(0, 2, 3, 1), n, h * w, c).view(n, c, h, w), None, None, None, None

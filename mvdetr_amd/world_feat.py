@@ -114,16 +114,17 @@ class DeformableTransformerEncoder(nn.Module):
     def shared_reference(self):
         """``[L, Lq, 2]`` when every (query, level) holds ONE point repeated n_points times -- MVDeTr's map with all
         heights 0, mvdetr.py:49-58 -- else None.  Derived from ``reference_points`` and re-derived whenever that buffer is
-        replaced or written in place (keyed by tensor identity and ``_version``: a comparison per forward, no device
+        replaced or written in place (keyed by the tensor object and its ``_version``: a comparison per forward, no device
         sync unless the key moved), so the fused path can never sample a stale copy of the map."""
         rp = self.reference_points
         if rp is None:
             return None
-        key = (id(rp), rp._version)
-        if key != self._reference_key:
+        # (the source tensor itself is kept and compared with `is` -- an id() can be reused by a later tensor of the same shape)
+        key = self._reference_key
+        if key is None or key[0] is not rp or key[1] != rp._version:
             same = bool((rp == rp[..., :1, :]).all())
             self.reference_shared = rp[..., 0, :].transpose(0, 1).contiguous() if same else None
-            self._reference_key = key
+            self._reference_key = (rp, rp._version)
         return self.reference_shared
 
     def forward(self, src, spatial_shapes, level_start_index, valid_ratios=None, pos=None, padding_mask=None):

@@ -101,3 +101,27 @@ def test_config0_at_the_real_multiviewx_geometry_on_the_cpu():
     scale = want.abs().max().item()
     assert scale > 1e-3
     assert (got - want).abs().max().item() < 1e-4 * max(1.0, scale)
+
+
+def test_model_copies_and_pickles_without_its_upload_state():
+    """the per-device staging buffers / events / cached uploads of MVDeTr.frame_proj_mats are run-time state,
+    not part of the model: deepcopy and pickle leave them behind, and the host copy of proj_mats follows the buffer object
+    (`is` + version), not its id()."""
+    import copy
+    import io
+    from mvdetr_amd.model import build_model
+    m = build_model("mini", seed=0).eval()
+    M = torch.eye(3).repeat(1, m.num_cam, 1, 1)
+    p0 = m.frame_proj_mats(M)
+    m._transient[("cuda", 0, 0)] = object()                      # stands in for pinned buffers + events
+    m2 = copy.deepcopy(m)
+    assert m2._transient == {} and m2._proj_host_src is None
+    assert torch.equal(m2.frame_proj_mats(M), p0)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3._transient == {} and torch.equal(m3.frame_proj_mats(M), p0)
+    # replacing the buffer is seen even if the new tensor were to get the old one's id: the cache holds the object
+    m.proj_mats = m.proj_mats.clone() * 2.0
+    assert not torch.equal(m.frame_proj_mats(M), p0)

@@ -387,6 +387,29 @@ def test_auto_dispatch_rules(msda_impl):
         assert MSDA.last_forward_impl() == "gather"
 
 
+@pytest.mark.parametrize("L,D", [(7, 16), (6, 32)])
+def test_auto_stands_down_tile_by_tile(msda_impl, L, D):
+    """Round 4: no probe kernel in front of the public-contract forward.  msda_fwd_group2 looks at every tile's own taps
+    (the sample that also places its windows) and, in `auto`, a tile whose taps are mostly far from their cells computes its
+    outputs in the gather formulation inside the same launch.  Mixed input: the left half of every camera's map samples near
+    its cells, the right half anywhere -- both kinds of job in one launch, every query against the oracle; forced `tile`
+    (windows everywhere, far taps one by one) must agree."""
+    MSDA = msda_impl
+    H, W, M = 20, 48, 128 // D
+    value, shapes, lsi, loc, aw = encoder_msda_inputs(L, H, W, M, D, 4, seed=11, noise_px=1.0)
+    g = torch.Generator().manual_seed(12)
+    far = torch.rand(loc.shape, generator=g) * 1.2 - 0.1
+    right = (torch.arange(H * W) % W >= W // 2).repeat(L)                       # per query: right half of its camera's map
+    loc = torch.where(right[None, :, None, None, None, None], far, loc).contiguous()
+    want = c_oracle.msda_forward(value.double(), shapes, lsi, loc.double(), aw.double())
+    for impl in ("auto", "tile"):
+        MSDA.set_forward_impl(impl)
+        got = MSDA.ms_deform_attn_forward(*dev(value, shapes, lsi, loc, aw), 64)
+        assert MSDA.last_forward_impl() == "tile" and MSDA.last_forward_kernel().startswith("msda_fwd_group2")
+        assert (got.cpu().double() - want).abs().max().item() < FP32_TOL, impl
+    MSDA.set_forward_impl("auto")
+
+
 # ---- backward at encoder shapes (partial tiles, misses, batch, NaN) vs the oracle ------------------------------------
 def _away_from_texel_centres(loc, shapes, eps=1e-4):
     """1.0 where a tap's pixel coordinates are both > eps away from an integer.  The bilinear blend is

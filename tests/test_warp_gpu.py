@@ -187,9 +187,9 @@ def _count_kernel_calls(monkeypatch):
     seen = []
     real = warp_mod._launch
 
-    def spy(name, a, M, n, c, h, w, H, W, layout, out):
+    def spy(name, a, M, n, c, h, w, H, W, layout, out, **kw):
         seen.append((name, layout))
-        return real(name, a, M, n, c, h, w, H, W, layout, out)
+        return real(name, a, M, n, c, h, w, H, W, layout, out, **kw)
     monkeypatch.setattr(warp_mod, "_launch", spy)
     return seen
 
@@ -289,7 +289,7 @@ def test_kernel_name_per_layout_route(warp):
         leaf = s_in.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
         out = warp(leaf, M, (120, 360), channels_last_out=nhwc)
         out.backward(torch.ones_like(out))
-        assert _last_kernel() == "warp_bwd_gather"
+        assert _last_kernel() == "warp_bwd_gather[planned]"         # autograd: plan kept per matrix tensor (ops/warp.py)
     leaf = src[:, :37].detach().clone().requires_grad_(True)
     warp(leaf, M, (120, 360)).sum().backward()
     assert _last_kernel() == "warp_bwd<NCHW>"
@@ -440,7 +440,7 @@ def test_stress16_size_forward_and_adjoint(warp):
     for leaf in (src.cuda().requires_grad_(True), src_cl.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)):
         out = warp(leaf, M, (H, W), channels_last_out=True)
         (gs,) = torch.autograd.grad(out, leaf, go)
-        assert _last_kernel() == "warp_bwd_gather"
+        assert _last_kernel() == "warp_bwd_gather[planned]"
         lhs = (go.double() * out.detach().double()).sum().item()
         rhs = (gs.double() * leaf.detach().double()).sum().item()
         assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0) + 1e-2
@@ -489,3 +489,72 @@ def test_perf_guard_every_route_within_4x_of_a_copy(warp):
     go = torch.randn(7, 120, 360, 128, device="cuda")
     us = _time_us(lambda: _bwd_cl(go, M, 7, 128, 90, 160))
     assert us <= 6.0 * copy_us + 100.0, f"gather backward: {us:.0f} us against a {copy_us:.0f} us copy"
+
+
+def test_planned_backward_equals_the_one_call_entry_and_the_plan_is_reused(warp):
+    """ABI 10: mvdetr_warp_backward_plan_* + mvdetr_warp_perspective_backward_planned_* (what autograd calls) give the
+    bits of mvdetr_warp_perspective_backward_*; the plan is built once per matrix tensor and survives until the matrices
+    change (in-place write -> version counter -> a new plan)."""
+    from mvdetr_amd.ops import warp as warp_mod
+    M = wildtrack_mats(None).float().cuda()
+    src = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(5)).cuda().contiguous(memory_format=torch.channels_last)
+    go = torch.randn(7, 120, 360, 128, generator=torch.Generator().manual_seed(6)).cuda()
+    plain = _bwd_cl(go, M, 7, 128, 90, 160)
+    assert _last_kernel() == "warp_bwd_gather"
+    warp_mod._plans.entries.clear()
+    grads = []
+    for _ in range(3):
+        leaf = src.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+        warp(leaf, M, (120, 360), channels_last_out=True).backward(go)
+        assert _last_kernel() == "warp_bwd_gather[planned]"
+        grads.append(leaf.grad.permute(0, 2, 3, 1))
+    assert len(warp_mod._plans.entries) == 1                          # one plan for the three calls
+    for g in grads:
+        assert torch.equal(g, plain)
+    plan0 = warp_mod._plans.entries[0][3]
+    M.mul_(1.0)                                                        # same values, new version: the plan is rebuilt
+    leaf = src.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+    warp(leaf, M, (120, 360), channels_last_out=True).backward(go)
+    assert len(warp_mod._plans.entries) == 2 and warp_mod._plans.entries[0][3] is not plan0
+    assert torch.equal(leaf.grad.permute(0, 2, 3, 1), plain)
+    # other matrices through the cache: their own gradient, not the cached one's
+    M2 = wildtrack_mats(4).float().cuda()
+    leaf = src.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+    warp(leaf, M2, (120, 360), channels_last_out=True).backward(go)
+    assert torch.equal(leaf.grad.permute(0, 2, 3, 1), _bwd_cl(go, M2, 7, 128, 90, 160))
+
+
+def test_backward_cost_is_bounded_with_the_horizon_in_view(warp):
+    """a source square just below the horizon has a far-end image millions of pixels long; the scans' fast path
+    clamped its lines to the grid but not their length, so one block could walk up to 2e9 candidates (seconds).  Costs above
+    H*W now go to the clipping path.  Guard: horizon-in-view matrices at Wildtrack size take no longer than a few times the
+    ordinary geometry."""
+    import time
+    n, c, h, w, H, W = 4, 128, 90, 160, 120, 360
+    go = torch.randn(n, H, W, c, generator=torch.Generator().manual_seed(3)).cuda()
+    # the horizon (the pre-image of the line at infinity) runs through the source image a little above its lower edge
+    Ms = []
+    for k in range(n):
+        A = torch.tensor([[2.0, 0.1 * k, 5.0], [0.05, 2.2, -3.0], [1e-4 * k, 0.012 + 0.001 * k, -1.0]], dtype=torch.float64)
+        Ms.append(A)
+    Mh = torch.stack(Ms)
+    ordinary = wildtrack_mats(None)[:n]
+
+    def run(M):
+        _bwd_cl(go, M.float(), n, c, h, w)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            g = _bwd_cl(go, M.float(), n, c, h, w)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3, g
+
+    t_ord, _ = run(ordinary)
+    t_hor, g = run(Mh)
+    assert torch.isfinite(g).all()
+    assert t_hor < max(20 * t_ord, 5e-3), (t_hor, t_ord)
+    # and it is still the right gradient: adjoint identity against the forward on the same matrices
+    x = torch.randn(n, h, w, c, generator=torch.Generator().manual_seed(4)).cuda()
+    y = warp(x.permute(0, 3, 1, 2), Mh, (H, W), channels_last_out=True)
+    lhs, rhs = (y.double() * go.double()).sum().item(), (x.double() * g.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2
