@@ -136,6 +136,38 @@ int mvdetr_msda_backward_f64(void *stream, const double *grad_col, const double 
                              int num_query, int num_point, double *grad_value,
                              double *grad_sampling_loc, double *grad_attn_weight);
 
+/* ---- Fused TRAINING pair (ABI 10): MSDeformAttn.forward / backward with the module arithmetic inside the kernels --------
+ * What the reference runs when gradients are needed -- softmax and location arithmetic in torch (ms_deform_attn.py:100-107),
+ * the extension's forward / backward on the materialised sampling_locations (135 MB at Wildtrack size) and
+ * attention_weights (68 MB) (func.py:21-38, cuh:237-299, 956-1327), and torch's backward of that arithmetic -- as two calls
+ * on the module's RAW Linear outputs:
+ *   raw   [batch, Lq, >= M*L*P*3]  one tensor, per query [L][M/g][g*P*2 offsets | g*P logits], g = 32 / channels heads per
+ *         128-byte slice (the layout MultiScaleDeformableAttention.slice_major_rows(level_outer=True) gives the GEMM);
+ *         raw_query_stride floats between queries
+ *   reference_points [batch or 1, L, Lq, 2]  ONE point per (query, level), level-major (MVDeTr's map; ref_batch_stride 0 when
+ *         shared by the batch)
+ * Shapes: queries = tokens (Lq = spatial_size), 6 or 7 levels OF EQUAL SHAPE (the caller's promise: on other shapes the
+ * outputs are NaN), 4 points, 16-channel heads; mvdetr_msda_fused_train_supported says whether a call qualifies (1 / 0).
+ * forward: out [batch, Lq, M*D] as mvdetr_msda_forward_fused_f32, plus stats [batch, Lq, M, 2] = (maximum logit,
+ *          1 / sum of exp(logit - maximum)) of every (query, head), which the backward needs to rebuild the weights.
+ * backward: grad_value [batch, S, M, D] (ACCUMULATED: zero it first) and grad_raw [batch, Lq, raw_query_stride] (the
+ *          M*L*P*3 leading columns of every query are written, in raw's layout) from grad_output, the same inputs, stats and
+ *          the forward's out (softmax backward: d logit = a (d a - <grad_output, out>)).
+ * Return 0, hipErrorNotSupported (801) for shapes / alignments outside the above, another hipError_t on failure. */
+int mvdetr_msda_fused_train_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                      int num_point);
+int mvdetr_msda_forward_fused_train_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                        const int64_t *level_start_index, const float *reference_points,
+                                        int64_t ref_batch_stride, const float *raw, int raw_query_stride, int batch,
+                                        int spatial_size, int num_heads, int channels, int num_levels, int num_point,
+                                        float *out, float *stats);
+int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const float *value,
+                                   const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                   const float *reference_points, int64_t ref_batch_stride, const float *raw,
+                                   int raw_query_stride, const float *stats, const float *out, int batch, int spatial_size,
+                                   int num_heads, int channels, int num_levels, int num_point, float *grad_value,
+                                   float *grad_raw);
+
 /* ---- Feature -> ground-plane homography warp ---------------------------------------------------
  * Replaces the third-party call kornia.warp_perspective(src, M, dsize, mode='bilinear',
  * padding_mode='zeros', align_corners=False) at multiview_detector/models/mvdetr.py:194-195

@@ -44,6 +44,9 @@ SIGNATURES = {
     "mvdetr_msda_forward_fused_f32": (_MSDA_FUSED, _i),
     "mvdetr_msda_fused_levels_supported": ([_i] * 9, _i),
     "mvdetr_msda_forward_fused_levels_f32": (_MSDA_FUSED_LEVELS, _i),
+    "mvdetr_msda_fused_train_supported": ([_i] * 7, _i),
+    "mvdetr_msda_forward_fused_train_f32": ([_vp] * 5 + [ctypes.c_int64, _vp] + [_i] * 7 + [_vp, _vp], _i),
+    "mvdetr_msda_backward_fused_f32": ([_vp] * 6 + [ctypes.c_int64, _vp, _i, _vp, _vp] + [_i] * 6 + [_vp, _vp], _i),
     "mvdetr_msda_backward_f32": (_MSDA_BWD, _i),
     "mvdetr_msda_backward_f64": (_MSDA_BWD, _i),
     "mvdetr_add_layernorm_f32": ([_vp] * 5 + [ctypes.c_int64, _i, ctypes.c_float, _vp], _i),

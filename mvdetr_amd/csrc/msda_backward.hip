@@ -189,6 +189,40 @@ int mvdetr_msda_backward_f32(void *stream, const float *grad_col, const float *v
                                          grad_sampling_loc, grad_attn_weight);
 }
 
+int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const float *value,
+                                   const int64_t *spatial_shapes, const int64_t *level_start_index,
+                                   const float *reference_points, int64_t ref_batch_stride, const float *raw,
+                                   int raw_query_stride, const float *stats, const float *out, int batch, int spatial_size,
+                                   int num_heads, int channels, int num_levels, int num_point, float *grad_value,
+                                   float *grad_raw)
+{
+    using namespace mvdetr;
+    if (batch < 0 || spatial_size < 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_point <= 0)
+        return (int)hipErrorInvalidValue;
+    if ((int64_t)batch * spatial_size == 0) return 0;
+    if (!grad_output || !value || !spatial_shapes || !level_start_index || !reference_points || !raw || !stats || !out ||
+        !grad_value || !grad_raw)
+        return (int)hipErrorInvalidValue;
+    if (!mvdetr_msda_fused_train_supported(batch, spatial_size, num_heads, channels, num_levels, spatial_size, num_point) ||
+        channels != 16)
+        return (int)hipErrorNotSupported;
+    if (raw_query_stride < num_heads * num_levels * num_point * 3 || raw_query_stride % 4) return (int)hipErrorInvalidValue;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(grad_output) | reinterpret_cast<uintptr_t>(value) |
+                         reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(out) |
+                         reinterpret_cast<uintptr_t>(grad_value) | reinterpret_cast<uintptr_t>(grad_raw);
+    if ((al & 15) || (reinterpret_cast<uintptr_t>(reference_points) & 7) || (reinterpret_cast<uintptr_t>(stats) & 7) ||
+        (ref_batch_stride & 1))
+        return (int)hipErrorNotSupported;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc = msda_backward_value_tile_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                            reference_points, ref_batch_stride, stats, batch, spatial_size, num_heads,
+                                            channels, num_levels, grad_value);
+    if (rc) return rc;
+    return msda_backward_fused_sampling(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                        reference_points, ref_batch_stride, stats, out, batch, spatial_size, num_heads,
+                                        channels, num_levels, grad_raw);
+}
+
 int mvdetr_msda_backward_f64(void *stream, const double *grad_col, const double *value,
                              const int64_t *spatial_shapes, const int64_t *level_start_index,
                              const double *sampling_loc, const double *attn_weight, int batch,

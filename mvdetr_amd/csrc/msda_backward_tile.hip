@@ -57,12 +57,16 @@ extern "C" int mvdetr_debug_bwd_trace(unsigned long long *host, int n)
 
 namespace mvdetr {
 
-template <int D>
+// FUSED = 1 (the fused training backward, msda_backward_fused.hip): `loc` is the module's RAW tensor [.., Lq, L, M/g,
+// (g*P*2 offsets | g*P logits)] (query stride raw_q floats), `aw` the forward's softmax statistics [.., Lq, M, (max, 1/sum)],
+// `ref` one reference point per (query, level), level-major [B or 1, L, Lq, 2]: locations and weights are recomputed per tap
+// with the forward's own expressions, and the windows follow the tile's taps as in the forward (no probe).
+template <int D, int FUSED>
 __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
     int L, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw,
-    const int *__restrict__ local_hits)
+    const int *__restrict__ local_hits, const float *__restrict__ ref, int64_t ref_bstride, int raw_q)
 {
     constexpr int TH = 4, TW = 32, R = 6, WH = TH + 2 * R, WW = TW + 2 * R, LCH = 16, P = TILE_P, THREADS = 256;
     constexpr int NTOK = WH * WW, NTOKP = NTOK + 4;           // channel stride = 4 (mod 32): the flush reads conflict-free
@@ -87,6 +91,12 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
     if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;
+    if (FUSED && !equal) {
+        // (the fused entry's callers promise equal level shapes: make the misuse loud)
+        for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < (int64_t)B * S * M * D; i += (int64_t)gridDim.x * THREADS)
+            grad_value[i] = __builtin_nanf("");
+        return;
+    }
     if (!equal) {
         // not this kernel's case: the lane-group backward (msda_backward_lanes.h) does all three gradients here,
         // and msda_bwd_sampling_tile, which sees the same shapes, stands down
@@ -101,6 +111,27 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
     const int jobs = per_level * HS * B * L, jobs8 = (jobs + 7) / 8;
     const float fW = (float)Wq, fH = (float)Hq;
+    const float iw = 1.f / fW, ih = 1.f / fH;
+    // sampling data of (query q, this job's head, level l): locations (x, y) x 4 points in la / lb, weights in wa
+    constexpr int HPS = 32 / D;
+    auto fetch = [&](int64_t q, int b, int head, int l, float4 &la, float4 &lb, float4 &wa) {
+        if constexpr (FUSED) {
+            const float *rp = loc + q * raw_q + (l * (M / HPS) + head / HPS) * (HPS * P * 3);
+            const float4 oa = *reinterpret_cast<const float4 *>(rp + (head % HPS) * P * 2);
+            const float4 ob = *reinterpret_cast<const float4 *>(rp + (head % HPS) * P * 2 + 4);
+            const float4 lg = *reinterpret_cast<const float4 *>(rp + HPS * P * 2 + (head % HPS) * P);
+            const float2 r = *reinterpret_cast<const float2 *>(ref + b * ref_bstride + ((int64_t)l * S + (q - (int64_t)b * S)) * 2);
+            const float2 st = *reinterpret_cast<const float2 *>(aw + (q * M + head) * 2);
+            la = make_float4(r.x + oa.x * iw, r.y + oa.y * ih, r.x + oa.z * iw, r.y + oa.w * ih);
+            lb = make_float4(r.x + ob.x * iw, r.y + ob.y * ih, r.x + ob.z * iw, r.y + ob.w * ih);
+            wa = make_float4(__expf(lg.x - st.x) * st.y, __expf(lg.y - st.x) * st.y, __expf(lg.z - st.x) * st.y, __expf(lg.w - st.x) * st.y);
+        } else {
+            const float *lp = loc + ((q * M + head) * L + l) * P * 2;
+            la = *reinterpret_cast<const float4 *>(lp);
+            lb = *reinterpret_cast<const float4 *>(lp + 4);
+            wa = *reinterpret_cast<const float4 *>(aw + ((q * M + head) * L + l) * P);
+        }
+    };
 
     int *const wsum = reinterpret_cast<int *>(win64 + (LCH / 2) * NTOKP);
     for (int i = tid; i < (LCH + 1) * NTOKP; i += THREADS) reinterpret_cast<int *>(win64)[i] = 0;
@@ -134,6 +165,33 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
         auto query = [&](int c) { return (int64_t)b * S + lsi[c] + cell; };
         int shx, shy;                                         // where this head's taps lie (locality probe)
         msda_probe_shift(local_hits, head, shx, shy);
+        if constexpr (FUSED) {
+            // no probe in front of the fused backward: every wave reduces the same sample (the tile's first two rows, camera
+            // 0, this level) to the head's mean tap displacement, as the forward does
+            const int sl = tid & 63;
+            const int s_qy = Y0 + sl / TW, s_qx = X0 + sl % TW;
+            float sx = 0.f, sy = 0.f, sn = 0.f;
+            if (s_qy < Hq && s_qx < Wq) {
+                float4 a0, b0, w0;
+                fetch((int64_t)b * S + lsi[0] + (int64_t)s_qy * Wq + s_qx, b, head, l, a0, b0, w0);
+                const float mx = 0.25f * ((a0.x + a0.z) + (b0.x + b0.z)) * fW - 0.5f - (float)s_qx;
+                const float my = 0.25f * ((a0.y + a0.w) + (b0.y + b0.w)) * fH - 0.5f - (float)s_qy;
+                if (mx == mx && my == my && fabsf(mx) < 64.f && fabsf(my) < 64.f) { sx = mx; sy = my; sn = 1.f; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sx += __shfl_xor(sx, o, 64);
+                sy += __shfl_xor(sy, o, 64);
+                sn += __shfl_xor(sn, o, 64);
+            }
+            const float tx_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
+            const float ty_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy)));
+            const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
+            if (tn > 0.f) {
+                shx = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf(tx_ / tn)));
+                shy = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf(ty_ / tn)));
+            }
+        }
         const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
         const int64_t level_base = ((int64_t)b * S + lsi[l]) * row;
@@ -151,11 +209,7 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = c0 + 2 * k + chalf < L ? c0 + 2 * k + chalf : L - 1;
-                const int64_t q = query(c);
-                const float *lp = loc + ((q * M + head) * L + l) * P * 2;
-                la8[k] = *reinterpret_cast<const float4 *>(lp);
-                lb8[k] = *reinterpret_cast<const float4 *>(lp + 4);
-                wa8[k] = *reinterpret_cast<const float4 *>(aw + ((q * M + head) * L + l) * P);
+                fetch(query(c), b, head, l, la8[k], lb8[k], wa8[k]);
             }
         };
         float gmax = 0.f, al = 0.f;
@@ -249,10 +303,7 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_win(
                 const float *gp = go + gofs + 4 * chalf;
                 g4[0] = *reinterpret_cast<const float4 *>(gp);        // channels 4*chalf .. +3
                 g4[1] = *reinterpret_cast<const float4 *>(gp + 8);    // and their partners, + 8
-                const float *lp = loc + ((q * M + head) * L + l) * P * 2;
-                la = *reinterpret_cast<const float4 *>(lp);
-                lb = *reinterpret_cast<const float4 *>(lp + 4);
-                wa = *reinterpret_cast<const float4 *>(aw + ((q * M + head) * L + l) * P);
+                fetch(q, b, head, l, la, lb, wa);
             };
             load_cam(0);                      // inactive lanes read cell 0's data and add nothing
             for (int c = 0; c < L; ++c) {
@@ -395,25 +446,26 @@ int msda_launch_locality_probe(hipStream_t st, const float *loc, const int64_t *
     return (int)hipGetLastError();
 }
 
-template <int D>
+template <int D, int FUSED>
 static int launch_value_win(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                             const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
-                            float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits)
+                            float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits, const float *ref,
+                            int64_t ref_bstride, int raw_q)
 {
     constexpr int LDS = (16 + 1) * (16 * 44 + 4) * 4;         // accumulators + weight mass
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_win<D>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_win<D, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_value_win<D>, 256, LDS) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_value_win<D, FUSED>, 256, LDS) != hipSuccess || per_cu < 1)
             per_cu = 3;
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    hipLaunchKernelGGL((msda_bwd_value_win<D>), dim3((unsigned)blocks), dim3(256), LDS, st, go, value, shapes, lsi, loc, aw,
-                       B, S, M, L, grad_value, grad_loc, grad_aw, local_hits);
+    hipLaunchKernelGGL((msda_bwd_value_win<D, FUSED>), dim3((unsigned)blocks), dim3(256), LDS, st, go, value, shapes, lsi, loc, aw,
+                       B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, ref, ref_bstride, raw_q);
     return (int)hipGetLastError();
 }
 
@@ -421,9 +473,18 @@ int msda_backward_value_tile(hipStream_t st, const float *go, const float *value
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                              float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits)
 {
-    if (D == 16) return launch_value_win<16>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits);
-    if (D == 32) return launch_value_win<32>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits);
+    if (D == 16) return launch_value_win<16, 0>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, nullptr, 0, 0);
+    if (D == 32) return launch_value_win<32, 0>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, nullptr, 0, 0);
     return (int)hipErrorInvalidValue;
+}
+
+// grad_value of the fused training backward: raw offsets / logits + the forward's statistics (see the kernel's header)
+int msda_backward_value_tile_fused(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                   const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                   const float *stats, int B, int S, int M, int D, int L, float *grad_value)
+{
+    if (D == 16) return launch_value_win<16, 1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr, nullptr, ref, ref_bstride, raw_q);
+    return (int)hipErrorNotSupported;
 }
 
 }  // namespace mvdetr

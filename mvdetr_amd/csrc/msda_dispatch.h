@@ -48,12 +48,19 @@ bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool 
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
                             int layout, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
-                            int M, int D, int L, float *out);
+                            int M, int D, int L, float *out, float *stats = nullptr);
 
 // grad_value of encoder-shaped fp32 calls through fixed-point LDS windows (msda_backward_tile.hip)
 int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                              float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits);
+// the two halves of the fused training backward (msda_backward_tile.hip, msda_backward_fused.hip)
+int msda_backward_value_tile_fused(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                   const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                   const float *stats, int B, int S, int M, int D, int L, float *grad_value);
+int msda_backward_fused_sampling(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                 const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                 const float *stats, const float *out_fwd, int B, int S, int M, int D, int L, float *grad_raw);
 // device-side locality probe shared by the kernels of a call (stream-ordered scratch of MSDA_PROBE_INTS ints):
 //   probe[0]              how many of MSDA_PROBE_SAMPLES sampled taps lie within MSDA_PROBE_RADIUS pixels of their own query cell
 //   probe[1 + 3 m + 0..2] for head m (< MSDA_PROBE_MAXHEADS): sum of the sampled taps' x / y displacement from their own cell in

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "../../include/mvdetr_ops.h"
 #include "msda_dispatch.h"
+#include "msda_tile.h"
 #include "msda_gather_body.h"
 #include <atomic>
 #include <stdlib.h>
@@ -196,13 +197,13 @@ int mvdetr_msda_forward_fused_f32(void *stream, const float *value, const int64_
                                                 out);
 }
 
-int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const int64_t *spatial_shapes,
-                                         const int64_t *level_start_index, const float *reference_points,
-                                         int64_t ref_batch_stride, const float *sampling_offsets,
-                                         const float *attn_logits, int level_major, int offsets_query_stride,
-                                         int logits_query_stride, int query_level_begin, int query_level_end,
-                                         int batch, int spatial_size, int num_heads, int channels, int num_levels,
-                                         int num_query, int num_point, float *out)
+static int fused_entry(void *stream, const float *value, const int64_t *spatial_shapes,
+                       const int64_t *level_start_index, const float *reference_points,
+                       int64_t ref_batch_stride, const float *sampling_offsets,
+                       const float *attn_logits, int level_major, int offsets_query_stride,
+                       int logits_query_stride, int query_level_begin, int query_level_end,
+                       int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                       int num_query, int num_point, float *out, float *stats)
 {
     using namespace mvdetr;
     const int dense_l = num_heads * num_levels * num_point * 2, dense_w = num_heads * num_levels * num_point;
@@ -241,7 +242,48 @@ int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const
                                    reference_points, ref_batch_stride, sampling_offsets, attn_logits,
                                    level_major, offsets_query_stride, logits_query_stride, query_level_begin,
                                    query_level_end, num_query, batch, spatial_size, num_heads, channels, num_levels,
-                                   out);
+                                   out, stats);
+}
+
+int mvdetr_msda_forward_fused_levels_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                         const int64_t *level_start_index, const float *reference_points,
+                                         int64_t ref_batch_stride, const float *sampling_offsets,
+                                         const float *attn_logits, int level_major, int offsets_query_stride,
+                                         int logits_query_stride, int query_level_begin, int query_level_end,
+                                         int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                         int num_query, int num_point, float *out)
+{
+    return fused_entry(stream, value, spatial_shapes, level_start_index, reference_points, ref_batch_stride, sampling_offsets,
+                       attn_logits, level_major, offsets_query_stride, logits_query_stride, query_level_begin, query_level_end,
+                       batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, out, nullptr);
+}
+
+int mvdetr_msda_fused_train_supported(int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                      int num_point)
+{
+    using namespace mvdetr;
+    // what msda_fwd_group2 and the fused backward take: 6 or 7 levels (of equal shape: the caller's promise), 16- or
+    // 32-channel heads, 4 points, queries = tokens, 32-bit offsets inside one batch element
+    if (!msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, true, 0, num_levels)) return 0;
+    if (!(num_levels == 6 || num_levels == 7) || channels != 16 || !msda_group_supported(channels, num_levels)) return 0;
+    return (int64_t)spatial_size * num_heads * num_levels * num_point * 3 < ((int64_t)1 << 30) ? 1 : 0;
+}
+
+int mvdetr_msda_forward_fused_train_f32(void *stream, const float *value, const int64_t *spatial_shapes,
+                                        const int64_t *level_start_index, const float *reference_points,
+                                        int64_t ref_batch_stride, const float *raw, int raw_query_stride, int batch,
+                                        int spatial_size, int num_heads, int channels, int num_levels, int num_point,
+                                        float *out, float *stats)
+{
+    if (!stats || !raw) return (int)hipErrorInvalidValue;
+    if (!mvdetr_msda_fused_train_supported(batch, spatial_size, num_heads, channels, num_levels, spatial_size, num_point))
+        return (int)hipErrorNotSupported;
+    const int hps = channels == 16 ? 2 : 1;
+    // layout: the slice-interleaved raw tensor with the level outermost (bits 2 and 4), one reference point per
+    // (query, level), level-major (bits 1 and 3)
+    return fused_entry(stream, value, spatial_shapes, level_start_index, reference_points, ref_batch_stride, raw,
+                       raw + hps * num_point * 2, 2 | 4 | 8 | 16, raw_query_stride, raw_query_stride, 0, num_levels, batch,
+                       spatial_size, num_heads, channels, num_levels, spatial_size, num_point, out, stats);
 }
 
 int mvdetr_msda_forward_f32(void *stream, const float *value, const int64_t *spatial_shapes,

@@ -46,17 +46,20 @@ constexpr int GROUP2_DEPTH = 2;
 
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
-                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits, bool standdown)
+                       SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits, bool standdown,
+                       float *stats)
 {
     const int opts = group_opts(fused) | ((standdown && !fused) ? GROUP_OPT_STANDDOWN : 0);
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts
-    if (L >= 9 && L <= 16)             // many cameras: 4 lane groups x up to 4 cameras (msda_forward_group_many.hip)
+    if (L >= 9 && L <= 16) {           // many cameras: 4 lane groups x up to 4 cameras (msda_forward_group_many.hip)
+        if (stats) return (int)hipErrorNotSupported;
         return msda_forward_group_many(st, value, shapes, lsi, off, logit, ref, ref_bstride, fused, lay, B, S, M, D, L, out,
                                        local_hits, opts);
+    }
     // 6 / 7 cameras: the software-pipelined kernel (msda_group2_kernel.h) for every entry -- fused (raw offsets / logits, one
     // or P reference points per (query, level)) and the public contract (final locations / weights)
-#define G2(CFG, LL) (fused == 2 ? launch_group2<CFG, LL, 2, GROUP2_DEPTH>(GROUP_ARGS) : fused ? launch_group2<CFG, LL, 1, GROUP2_DEPTH>(GROUP_ARGS) \
-                                                                                           : launch_group2<CFG, LL, 0, GROUP2_DEPTH>(GROUP_ARGS))
+#define G2(CFG, LL) (fused == 2 ? launch_group2<CFG, LL, 2, GROUP2_DEPTH>(GROUP_ARGS, stats) : fused ? launch_group2<CFG, LL, 1, GROUP2_DEPTH>(GROUP_ARGS, stats) \
+                                                                                                  : launch_group2<CFG, LL, 0, GROUP2_DEPTH>(GROUP_ARGS))
     if (D == 16 && L == 7) return G2(GWide16, 7);
     if (D == 16 && L == 6) return G2(GWide16, 6);
     if (D == 32 && L == 7) return G2(GWide32, 7);

@@ -136,7 +136,7 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
 int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *ref, int64_t ref_bstride, const float *offsets, const float *logits,
                             int layout, int qstride_l, int qstride_w, int ql0, int ql1, int Lq, int B, int S,
-                            int M, int D, int L, float *out)
+                            int M, int D, int L, float *out, float *stats)
 {
     const int level_major = layout & 1, shared_ref = layout & 2, slice_major = layout & 4, ref_level_major = layout & 8;
     const int P = TILE_P;
@@ -168,7 +168,8 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     const bool all_levels = ql0 == 0 && ql1 == L;
     if (all_levels && msda_group_supported(D, L) && msda_group_fits(S, M * D, lay) && !narrow_slices())
         return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
-                                  M, D, L, out);
+                                  M, D, L, out, nullptr, false, stats);
+    if (stats) return (int)hipErrorNotSupported;            // the training entry exists where msda_fwd_group2 takes the call
     return shared_ref ? dispatch_tile<2>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
                                          QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out)
                       : dispatch_tile<1>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,

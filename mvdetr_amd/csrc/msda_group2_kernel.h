@@ -68,7 +68,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
     const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M,
-    float *__restrict__ out, const int *__restrict__ local_hits, int opts)
+    float *__restrict__ out, const int *__restrict__ local_hits, int opts, float *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
     GROUP_STAMP(0);
@@ -95,6 +95,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
         using Fallback = TileCfg<Cfg::D, 32, 8, 16, 6, Cfg::THREADS>;
         msda_fwd_tile_body<Fallback, FUSED>(win, value, shapes, lsi, off, logit, ref, ref_bstride, lay,
                                             QueryLevels{0, L, S}, B, S, M, L, out);
+        // (the training entry needs equal level shapes -- its caller checks; statistics this path cannot give are NaN)
+        if (stats)
+            for (int64_t i = (int64_t)blockIdx.x * Cfg::THREADS + threadIdx.x; i < (int64_t)B * S * M * 2; i += (int64_t)gridDim.x * Cfg::THREADS)
+                stats[i] = __builtin_nanf("");
         return;
     }
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
@@ -485,6 +489,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
                     }
                 }
                 const float inv = FUSED ? 1.f / s.y : 1.f;
+                // training (mvdetr_msda_forward_fused_train_f32): the softmax statistics of (query, head) -- running maximum
+                // and reciprocal sum -- for the fused backward, which recomputes the weights from the raw logits
+                if (FUSED && stats && ch_off == 0)
+                    *reinterpret_cast<float2 *>(stats + ((cq + cell) * M + head) * 2) = make_float2(s.x, inv);
                 float *o = out + cq * row + (cell * (unsigned)row + (unsigned)(head * D + ch_off));
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
@@ -500,7 +508,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
 template <typename Cfg, int NG, int FUSED, int DEPTH>
 static int launch_group2(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                          const float *off, const float *logit, const float *ref, int64_t ref_bstride,
-                         SamplingLayout lay, int B, int S, int M, float *out, const int *local_hits, int opts)
+                         SamplingLayout lay, int B, int S, int M, float *out, const int *local_hits, int opts,
+                         float *stats = nullptr)
 {
     constexpr int FB = TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
     constexpr int LDS = Group2Lds<Cfg, NG>::BYTES > FB ? Group2Lds<Cfg, NG>::BYTES : FB;
@@ -519,7 +528,7 @@ static int launch_group2(hipStream_t st, const float *value, const int64_t *shap
     }();
     static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_group2<Cfg, NG, FUSED, DEPTH>));
     msda_note_forward_kernel("msda_fwd_group2[pipelined taps, LDS-DMA windows]", &res);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts, stats);
     return (int)hipGetLastError();
 }
 

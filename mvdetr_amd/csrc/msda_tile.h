@@ -84,7 +84,7 @@ inline bool msda_group_fits(int S, int row, const SamplingLayout &lay)
 int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                        const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                        SamplingLayout lay, int B, int S, int M, int D, int L, float *out,
-                       const int *local_hits = nullptr, bool standdown = false);
+                       const int *local_hits = nullptr, bool standdown = false, float *stats = nullptr);
 // its many-camera instantiations (msda_forward_group_many.hip); `opts`: GROUP_OPT_* of msda_group_kernel.h
 int msda_forward_group_many(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,

@@ -203,6 +203,63 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, refer
     return out
 
 
+def fused_train_supported(B, S, M, D, num_levels, num_query, num_point) -> bool:
+    """True when the fused TRAINING pair takes a call of these dimensions (CUDA fp32 tensors, equal level shapes and one
+    reference point per (query, level) are the caller's to check): include/mvdetr_ops.h."""
+    return bool(_lib.lib().mvdetr_msda_fused_train_supported(B, S, M, D, num_levels, num_query, num_point))
+
+
+def _train_args(value, spatial_shapes, level_start_index, reference_points, raw):
+    _check_inputs([("value", value), ("spatial_shapes", spatial_shapes), ("level_start_index", level_start_index),
+                   ("reference_points", reference_points)])
+    B, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    if value.dtype != torch.float32 or raw.dtype != torch.float32 or reference_points.dtype != torch.float32:
+        raise RuntimeError("the fused training pair is float32")
+    if tuple(reference_points.shape[1:]) != (L, S, 2) or reference_points.shape[0] not in (1, B):
+        raise RuntimeError("reference_points must be [B or 1, L, Lq, 2]: one point per (query, level), level-major")
+    if (raw.dim() != 3 or raw.shape[0] != B or raw.shape[1] != S or raw.shape[2] < M * L * 12 or not raw.is_cuda
+            or raw.stride(2) != 1 or (B > 1 and raw.stride(0) != raw.stride(1) * S)):
+        raise RuntimeError("raw must be a CUDA tensor [B, Lq, >= M*L*P*3], dense per query (slice_major_rows(level_outer=True))")
+    _meta(spatial_shapes, value.device), _meta(level_start_index, value.device)
+    rstride = reference_points.stride(0) if reference_points.shape[0] > 1 else 0
+    return B, S, M, D, L, rstride
+
+
+def ms_deform_attn_forward_fused_train(value, spatial_shapes, level_start_index, reference_points, raw):
+    """Forward of the fused training pair: -> (out [B, Lq, M*D], stats [B, Lq, M, 2]).  ``raw`` [B, Lq, M*L*12] is the
+    module's ONE GEMM output in the slice-interleaved, level-outermost layout; ``reference_points`` [B or 1, L, Lq, 2].
+    ``out`` equals ms_deform_attn_forward_fused(..., raw=raw, ref_level_major=True, raw_level_outer=True) bit for bit (the same
+    kernel); ``stats`` = (maximum logit, 1 / sum exp(logit - maximum)) per (query, head), for the backward."""
+    B, S, M, D, L, rstride = _train_args(value, spatial_shapes, level_start_index, reference_points, raw)
+    out = torch.empty((B, S, M * D), dtype=value.dtype, device=value.device)
+    stats = torch.empty((B, S, M, 2), dtype=value.dtype, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().mvdetr_msda_forward_fused_train_f32(
+            _lib.current_stream_ptr(value.device), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            reference_points.data_ptr(), rstride, raw.data_ptr(), raw.stride(1), B, S, M, D, L, 4, out.data_ptr(), stats.data_ptr())
+    _lib.check(rc, "ms_deform_attn_forward_fused_train")
+    return out, stats
+
+
+def ms_deform_attn_backward_fused(grad_output, value, spatial_shapes, level_start_index, reference_points, raw, stats, out):
+    """Backward of the fused training pair: -> (grad_value [B, S, M, D], grad_raw like ``raw``).  Softmax and location
+    arithmetic are differentiated inside the kernels; no sampling_locations / attention_weights tensor exists."""
+    B, S, M, D, L, rstride = _train_args(value, spatial_shapes, level_start_index, reference_points, raw)
+    for name, t_ in (("grad_output", grad_output), ("stats", stats), ("out", out)):
+        if not t_.is_cuda or t_.dtype != torch.float32 or not t_.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous CUDA float32 tensor")
+    grad_value = torch.zeros_like(value)                       # accumulated (LDS fixed point + fp32 atomics at the flush)
+    grad_raw = torch.empty_like(raw) if raw.shape[2] == M * L * 12 else torch.zeros_like(raw)
+    with torch.cuda.device(value.device):
+        rc = _lib.lib().mvdetr_msda_backward_fused_f32(
+            _lib.current_stream_ptr(value.device), grad_output.data_ptr(), value.data_ptr(), spatial_shapes.data_ptr(),
+            level_start_index.data_ptr(), reference_points.data_ptr(), rstride, raw.data_ptr(), raw.stride(1), stats.data_ptr(),
+            out.data_ptr(), B, S, M, D, L, 4, grad_value.data_ptr(), grad_raw.data_ptr())
+    _lib.check(rc, "ms_deform_attn_backward_fused")
+    return grad_value, grad_raw
+
+
 def slice_major_rows(M, L, P, D, level_outer=False):
     """Row order of the ONE Linear that produces the slice-interleaved ``raw`` tensor from the reference module's two:
     (rows of sampling_offsets.weight, rows of attention_weights.weight shifted by M*L*P*2), i.e. indices into

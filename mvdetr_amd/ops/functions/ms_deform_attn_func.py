@@ -34,6 +34,30 @@ class MSDeformAttnFunction(Function):
         return g_value, None, None, g_loc, g_aw, None
 
 
+class MSDeformAttnFusedFunction(Function):
+    """The fused TRAINING pair (no counterpart in the reference; SURVEY row f1 for the training path): MSDeformAttn.forward
+    from the module's raw offsets / logits, with softmax and location arithmetic (ms_deform_attn.py:100-107) inside the
+    kernels in both directions.  Inputs: value [B, S, M, D]; ``raw`` [B, Lq, M*L*12] -- the ONE Linear output in the
+    slice-interleaved, level-outermost layout (MSDA.slice_major_rows(level_outer=True)); ``reference_points`` [B or 1, L, Lq, 2].
+    Saves value, raw, the output and the softmax statistics [B, Lq, M, 2] -- not the 203 MB of sampling locations and
+    attention weights the unfused path keeps for its backward.  Gradients: value and raw; once-differentiable like the
+    reference's function (func.py:29)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, reference_points, raw):
+        out, stats = MSDA.ms_deform_attn_forward_fused_train(value, value_spatial_shapes, value_level_start_index,
+                                                             reference_points, raw)
+        ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index, reference_points, raw, stats, out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, start, ref, raw, stats, out = ctx.saved_tensors
+        g_value, g_raw = MSDA.ms_deform_attn_backward_fused(grad_output.contiguous(), value, shapes, start, ref, raw, stats, out)
+        return g_value, None, None, None, g_raw
+
+
 def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
     """Debug-only torch formulation kept for API parity with the reference
     (ms_deform_attn_func.py:41-61, "for debug and test only").

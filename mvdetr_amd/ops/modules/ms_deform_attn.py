@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import MultiScaleDeformableAttention as MSDA
-from ..functions import MSDeformAttnFunction
+from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction
 
 
 def _is_power_of_2(n):
@@ -53,6 +53,10 @@ class MSDeformAttn(nn.Module):
         self._cache_projection = False
         self._fused_cache = None
         self._fused_rows = None
+        # calls that need gradients take the fused TRAINING pair (raw offsets / logits in, their gradient out) where it
+        # applies; MVDETR_MSDA_FUSED_TRAIN=0 keeps the reference's unfused arithmetic + MSDeformAttnFunction
+        self.fused_training = os.environ.get("MVDETR_MSDA_FUSED_TRAIN", "1") != "0"
+        self._equal_levels = None
         # order of the fused path's raw tensor: runs [L, M/g] (level outermost) or [M/g, L] -- see slice_major_rows
         self.raw_level_outer = os.environ.get("MVDETR_MSDA_RAW_LAYOUT", "level") != "slice"
         self._reset_parameters()
@@ -100,6 +104,27 @@ class MSDeformAttn(nn.Module):
             b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).index_select(0, self._fused_rows)
         if self._cache_projection:
             self._fused_cache = (w, b)
+        return w, b
+
+    def _levels_equal(self, spatial_shapes):
+        """All levels of one shape (MVDeTr: levels = cameras)?  One device sync per shapes tensor, remembered for that
+        tensor object and version."""
+        c = self._equal_levels
+        if c is None or c[0]() is not spatial_shapes or c[1] != spatial_shapes._version:
+            eq = bool((spatial_shapes == spatial_shapes[:1]).all())
+            self._equal_levels = c = (weakref.ref(spatial_shapes), spatial_shapes._version, eq)
+        return c[2]
+
+    def _fused_projection_train(self):
+        """The same permuted [offsets | logits] Linear as _fused_projection, built under autograd: the row gather is
+        differentiable, so grad_raw reaches sampling_offsets / attention_weights through it."""
+        dev = self.sampling_offsets.weight.device
+        if self._fused_rows is None or self._fused_rows.device != dev:
+            rows = MSDA.slice_major_rows(self.n_heads, self.n_levels, self.n_points, self.d_model // self.n_heads,
+                                         level_outer=self.raw_level_outer)
+            self._fused_rows = torch.tensor(rows, dtype=torch.long, device=dev)
+        w = torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).index_select(0, self._fused_rows)
+        b = torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).index_select(0, self._fused_rows)
         return w, b
 
     def _check_lengths(self, spatial_shapes, len_in):
@@ -207,6 +232,24 @@ class MSDeformAttn(nn.Module):
                                         input_level_start_index, N, Len_q)
         if pending is not None:
             value = pending()
+        if (needs_grad and self.fused_training and self.raw_level_outer and query_levels is None and self.n_points == 4
+                and reference_points.dim() == 5 and reference_points.shape[-1] == 2
+                and query.is_cuda and query.dtype == torch.float32 and value.is_cuda and value.dtype == torch.float32
+                and reference_points.is_cuda and reference_points.dtype == torch.float32
+                and MSDA.fused_train_supported(N, Len_in, M, D, self.n_levels, Len_q, self.n_points)
+                and self._levels_equal(input_spatial_shapes)):
+            shared = shared_reference if shared_reference is not None else self._shared_reference(reference_points)
+            if shared is not None:
+                # training: ONE GEMM for offsets + logits, then the fused pair -- neither sampling locations nor attention
+                # weights are materialised, forward or backward (ms_deform_attn.py:100-114 + func.py:21-38 in two kernels
+                # each way)
+                w, b = self._fused_projection_train()
+                raw = F.linear(query, w, b)
+                value4 = value.view(N, Len_in, M, D).contiguous()
+                if value4.data_ptr() % 16 == 0 and raw.data_ptr() % 16 == 0:
+                    out = MSDeformAttnFusedFunction.apply(value4, input_spatial_shapes, input_level_start_index,
+                                                          shared.contiguous(), raw)
+                    return self.output_proj(out)
         value = value.view(N, Len_in, M, D)
         offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         weights = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
