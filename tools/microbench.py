@@ -114,6 +114,21 @@ def bench_msda(a, L, H, W, M, D, P, B, S, fwd_bytes, bwd_bytes):
                                                        query_levels=(0, n_own))
         report(f"msda_fwd_fused[{n_own} of {L} levels]", time_us(fn, a.iters), own_bytes)
 
+    # fused TRAINING pair: raw [B, Lq, M*L*12] in the level-outer slice layout in, gradient of the same tensor out; the
+    # byte counts are SURVEY 8d's for the unfused kernels it replaces (so the fractions compare like for like)
+    if not a.skip_bwd and MSDA.fused_train_supported(B, S, M, D, L, S, P):
+        rows = torch.tensor(MSDA.slice_major_rows(M, L, P, D, level_outer=True), device="cuda")
+        plain = torch.cat([off.permute(0, 1, 3, 2, 4, 5).reshape(B, S, -1), logit.permute(0, 1, 3, 2, 4).reshape(B, S, -1)], -1)
+        raw_t = plain.index_select(-1, rows).contiguous()
+        del plain
+        ref_lm = ref[:, :, :, 0, :].permute(0, 2, 1, 3).contiguous()         # [1, L, Lq, 2]
+        fn = lambda: MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw_t)  # noqa: E731
+        report("msda_fwd_fused_train (+stats)", time_us(fn, a.iters), fwd_bytes)
+        out_t, stats_t = fn()
+        go = torch.randn(B, S, M * D, device="cuda")
+        fn = lambda: MSDA.ms_deform_attn_backward_fused(go, value, shapes, lsi, ref_lm, raw_t, stats_t, out_t)  # noqa: E731
+        report("msda_bwd_fused (+memset)", time_us(fn, max(5, a.iters // 3)), bwd_bytes)
+
 
 
 def bench_warp(a, geom, L, C):
