@@ -16,7 +16,7 @@ Prints ONE JSON line (rank 0):
                    here with HIP events on the launching stream, against the 8 TB/s HBM peak;
                    `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes
                    (profiles/*_traffic.json), null when that file is absent
-  roofline_warp / roofline_warp_bwd / roofline_msda_bwd
+  roofline_warp / roofline_warp_bwd / roofline_msda_bwd / roofline_train_step
                    the other kernels SURVEY 8d names, same accounting (4*N*C*(h*w + H*W) bytes for the warp and its
                    gradient; 4*(Lq*M*D + 2*S*M*D + 6*Lq*M*L*P) for the MSDA backward), HIP events over 12 launches each,
                    measured on rank 0 after the timed region; roofline.code_object = registers / scratch (spill) bytes per
@@ -218,10 +218,29 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
         bbytes = 4 * (S * M_ * D_ + 2 * S * M_ * D_ + 6 * S * M_ * N * 4)   # 4 (Lq M D + 2 S M D + 6 Lq M L P)
         us, mn = time_launches(lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, gout, 64), launches)
         out["roofline_msda_bwd"] = roofline_entry(
-            "msda_bwd_value_win + msda_bwd_sampling_resident (+ memset of grad_value)" if (D_ == 16 and N <= 7)
-            else "msda_bwd_value_win + msda_bwd_sampling_groups (+ memset of grad_value)", us, mn, bbytes, launches,
+            "msda_bwd_value_tok + msda_bwd_sampling_resident (+ locality probe, memset of grad_value)" if (D_ == 16 and N <= 7)
+            else "msda_bwd_value_tok + msda_bwd_sampling_groups (+ locality probe, memset of grad_value)", us, mn, bbytes, launches,
             "MultiScaleDeformableAttention.ms_deform_attn_backward (public contract), SURVEY 8d's locality-realistic input: "
             "bias grid + N(0, 1 px) offsets, softmax(N(0,1)) weights")
+        del value, loc, aw, gout
+        # the fused TRAINING pair (what MSDeformAttn.forward runs when gradients are needed): forward from the raw offsets /
+        # logits + softmax statistics, backward to grad_value and the gradient of the raw tensor.  Bytes: SURVEY 8d's counts
+        # of the unfused forward + backward it replaces, so that the fraction compares like for like (the pair itself never
+        # materialises sampling_locations / attention_weights or their gradients).
+        if MSDA.fused_train_supported(1, S, M_, D_, N, S, 4):
+            from helpers import fused_train_inputs
+            value, shapes, lsi, ref_lm, raw, _ = [x.to(feat.device) for x in fused_train_inputs(N, hh, ww, M_, D_, 4, seed=0)]
+            gout = torch.randn(1, S, M_ * D_, device=feat.device)
+            fbytes = 4 * (S * M_ * D_ + 3 * S * M_ * N * 4 + S * M_ * D_)
+            o_, st_ = MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw)
+            us_f, mn_f = time_launches(lambda: MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw), launches)
+            us_b, mn_b = time_launches(lambda: MSDA.ms_deform_attn_backward_fused(gout, value, shapes, lsi, ref_lm, raw, st_, o_), launches)
+            out["roofline_train_step"] = roofline_entry(
+                "msda_fwd_group2 (+ statistics) ; msda_bwd_value_tok<fused> + msda_bwd_fused_sampling (+ memset of grad_value)",
+                us_f + us_b, mn_f + mn_b, fbytes + bbytes, launches,
+                "mvdetr_msda_forward_fused_train_f32 + mvdetr_msda_backward_fused_f32 on the same realistic input in raw form",
+                {"forward_us": round(us_f, 2), "backward_us": round(us_b, 2),
+                 "backward_frac": round(bbytes / (us_b * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)})
     return out
 
 
@@ -545,7 +564,8 @@ def main():
     }
     if a.parallel == "dp" and not a.no_kernel_rooflines and hasattr(model.world_feat, "encoder"):
         res.update(other_kernel_rooflines(model, geom, feat, proj, MSDA))
-        for key, tkey in (("roofline_warp", "warp_fwd"), ("roofline_warp_bwd", "warp_bwd"), ("roofline_msda_bwd", "msda_bwd")):
+        for key, tkey in (("roofline_warp", "warp_fwd"), ("roofline_warp_bwd", "warp_bwd"), ("roofline_msda_bwd", "msda_bwd"),
+                          ("roofline_train_step", "msda_train")):
             if key in res and tkey in traffic_all:           # (same source and caveats as roofline.traffic)
                 res[key]["traffic"], res[key]["traffic_source"] = traffic_all[tkey], traffic_src
         if "roofline_warp" in res and "warp_fwd_nchw" in traffic_all:

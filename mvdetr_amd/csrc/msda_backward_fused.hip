@@ -20,9 +20,9 @@
 // Structure: msda_fwd_group2's (msda_group2_kernel.h) -- a workgroup owns a (6 x 16 tile, 128-byte slice), stages one source
 // level's window in LDS per iteration (LDS-DMA), walks all NG cameras' queries over it with the tap reads as a software
 // pipeline (DEPTH pairs of ds_read_b128 in flight, order pinned in the source) -- with the accumulators replaced by the
-// cameras' grad_out rows (NG x 16 registers, loaded once per job) and four dot products per tap instead of four weighted
-// sums.  State per (lane, camera) in LDS: softmax maximum and reciprocal sum (from the forward), D.  Results go out tap by
-// tap (8 + 4 bytes) to where the inputs came from: a (query, level)'s runs of the four slices are three whole 128-byte
+// current camera's grad_out row (16 registers, double-buffered and re-read per level: keeping all NG rows spilled) and four
+// dot products per tap instead of four weighted sums.  State per (lane, camera) in LDS: softmax maximum and reciprocal sum (from the forward), D.  Results go out per (camera,
+// level) -- four taps, 32 + 16 bytes per lane -- to where the inputs came from: a (query, level)'s runs of the four slices are three whole 128-byte
 // lines, written by four jobs that run at the same time on one XCD.  Taps whose footprint leaves the window read zeros in
 // the stream and are redone from global memory after the level's stream (rare; their stores overwrite the stream's).
 //
@@ -37,6 +37,12 @@ __device__ __forceinline__ void buf_store2(__amdgpu_buffer_rsrc_t r, unsigned vo
     typedef unsigned u2 __attribute__((ext_vector_type(2)));
     const u2 v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
     __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b, float c, float d)
+{
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
 }
 __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a)
 {
@@ -178,8 +184,11 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
             }
         }
 
-        // the cameras' grad_out rows of this (cell, head), and per camera the softmax statistics and D = <grad_out, out>
-        float2v g[NG][2 * NV];
+        // per camera: the softmax statistics and D = <grad_out, out> of this (cell, head).  The grad_out rows themselves are
+        // NOT kept across the levels (7 x 16 registers: the first version of this kernel spilled 92 dwords per lane) -- a camera's
+        // row is re-read per level, one camera ahead of its taps (g_buf below): 4 more 16-byte loads per 32-tap stream.
+        const unsigned vo_g = (cell * (unsigned)row + (unsigned)(head * D)) * 4u;      // this lane's row inside a camera's block
+        const __amdgpu_buffer_rsrc_t rs_go = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(go + (int64_t)b * S * row), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
             const int64_t q = (int64_t)b * S + cam_q(c) + cell;
@@ -188,13 +197,10 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 float4 gv = make_float4(0, 0, 0, 0), ov = gv;
-                // registers hold the row in the lane's own read order: its k-th LDS read of a corner is chunk k ^ rot
                 if (active) {
-                    gv = *reinterpret_cast<const float4 *>(gp + ((k ^ rot) << 2));
-                    ov = *reinterpret_cast<const float4 *>(op + ((k ^ rot) << 2));
+                    gv = *reinterpret_cast<const float4 *>(gp + (k << 2));
+                    ov = *reinterpret_cast<const float4 *>(op + (k << 2));
                 }
-                g[c][2 * k] = (float2v){gv.x, gv.y};
-                g[c][2 * k + 1] = (float2v){gv.z, gv.w};
                 dq += (gv.x * ov.x + gv.y * ov.y) + (gv.z * ov.z + gv.w * ov.w);
             }
             if (tid < NCL) {
@@ -203,6 +209,18 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
                 dq_lane[c * NCL] = dq;
             }
         }
+        // grad_out rows, double-buffered by camera parity, in the lane's own read order: its k-th LDS read of a corner is
+        // chunk k ^ rot (inactive lanes read cell 0's row and their results are never stored)
+        float2v g_buf[2][2 * NV];
+        auto load_g = [&](int c) {
+            const unsigned so = (unsigned)(cam_q(c) * row) * 4u;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const float4 gv = buf_load4(rs_go, vo_g + (unsigned)((k ^ rot) << 4), so);
+                g_buf[c & 1][2 * k] = (float2v){gv.x, gv.y};
+                g_buf[c & 1][2 * k + 1] = (float2v){gv.z, gv.w};
+            }
+        };
 
         const int oy = Y0 + TH / 2 - WH / 2 + shift_y, ox = X0 + TW / 2 - WW / 2 + shift_x;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
@@ -252,15 +270,16 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
                 float2 ra = nr;
                 float aws[4] = {0.f, 0.f, 0.f, 0.f};
                 float dqs[2] = {0.f, 0.f};                    // D of the camera being consumed / issued
+                float gxy[2 * P], glg[P];                     // gradients of the (camera, level) being consumed
                 auto consume = [&](int m) {
                     const int c = m / (P * 8), p = (m / 8) % P, r = (m / 4) % 2, k = m % 4;
                     float4v &cl = ring[m % R][0], &cr = ring[m % R][1];
                     asm volatile("" : "+v"(cl), "+v"(cr));
                     if (m % 8 == 0) dl[0] = dl[1] = dr[0] = dr[1] = (float2v){0.f, 0.f};
-                    dl[r] = __builtin_elementwise_fma(g[c][2 * k], (float2v){cl.x, cl.y}, dl[r]);
-                    dl[r] = __builtin_elementwise_fma(g[c][2 * k + 1], (float2v){cl.z, cl.w}, dl[r]);
-                    dr[r] = __builtin_elementwise_fma(g[c][2 * k], (float2v){cr.x, cr.y}, dr[r]);
-                    dr[r] = __builtin_elementwise_fma(g[c][2 * k + 1], (float2v){cr.z, cr.w}, dr[r]);
+                    dl[r] = __builtin_elementwise_fma(g_buf[c & 1][2 * k], (float2v){cl.x, cl.y}, dl[r]);
+                    dl[r] = __builtin_elementwise_fma(g_buf[c & 1][2 * k + 1], (float2v){cl.z, cl.w}, dl[r]);
+                    dr[r] = __builtin_elementwise_fma(g_buf[c & 1][2 * k], (float2v){cr.x, cr.y}, dr[r]);
+                    dr[r] = __builtin_elementwise_fma(g_buf[c & 1][2 * k + 1], (float2v){cr.z, cr.w}, dr[r]);
                     asm volatile("" : "+v"(dl[r]), "+v"(dr[r]));
                     if (m % 8 == 7) {
                         // ---- the tap's four dots are complete: its three gradients go out
@@ -271,11 +290,20 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
                         const float da = top + wy * (bot - top);
                         const float dx = (d01 - d00) + wy * ((d11 - d10) - (d01 - d00));
                         const float dy = (d10 - d00) + wx * ((d11 - d01) - (d10 - d00));
-                        const unsigned so = (unsigned)(cam_q(c) * raw_q + l * l_stride) * 4u;
-                        buf_store2(rs_out, vo_l + p * 8u, so, a * dx, a * dy);
-                        buf_store1(rs_out, vo_w + p * 4u, so, a * (da - dqs[c & 1]));
+                        // a (camera, level)'s four taps leave together: 32 + 16 contiguous bytes per lane, three 16-byte stores
+                        // instead of eight 8- / 4-byte ones (the store path is bound by requests, not bytes)
+                        gxy[2 * p] = a * dx;
+                        gxy[2 * p + 1] = a * dy;
+                        glg[p] = a * (da - dqs[c & 1]);
+                        if (p == P - 1) {
+                            const unsigned so = (unsigned)(cam_q(c) * raw_q + l * l_stride) * 4u;
+                            buf_store4(rs_out, vo_l, so, gxy[0], gxy[1], gxy[2], gxy[3]);
+                            buf_store4(rs_out, vo_l + 16u, so, gxy[4], gxy[5], gxy[6], gxy[7]);
+                            buf_store4(rs_out, vo_w, so, glg[0], glg[1], glg[2], glg[3]);
+                        }
                     }
                 };
+                load_g(0);
 #pragma unroll
                 for (int c = 0; c < NG; ++c) {
                     la = na; lb = nb; wa = nw; ra = nr;
@@ -313,6 +341,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
                             __builtin_amdgcn_sched_barrier(0);
                             if (i >= DEPTH) consume(i - DEPTH);
                             __builtin_amdgcn_sched_barrier(0);
+                            // (the previous camera's last DEPTH pairs have been consumed: its buffer is free for the next one)
+                            if (p == 0 && j == DEPTH && c + 1 < NG) load_g(c + 1);
                         }
                     }
                 }
@@ -349,7 +379,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
                                 const int ko = (k ^ rot) << 2;
                                 const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch), c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
                                 const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch), c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
-                                const float2v ga = g[c][2 * k], gb = g[c][2 * k + 1];
+                                // (rare path: the camera's grad_out row comes from memory again, g_buf has moved on)
+                                const float4 gv = *reinterpret_cast<const float4 *>(go + ((int64_t)b * S + q) * row + head * D + ko);
+                                const float2v ga = {gv.x, gv.y}, gb = {gv.z, gv.w};
                                 d00 += (ga.x * c00.x + ga.y * c00.y) + (gb.x * c00.z + gb.y * c00.w);
                                 d01 += (ga.x * c01.x + ga.y * c01.y) + (gb.x * c01.z + gb.y * c01.w);
                                 d10 += (ga.x * c10.x + ga.y * c10.y) + (gb.x * c10.z + gb.y * c10.w);

@@ -43,7 +43,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifdef MVDETR_BWD_TRACE
+#ifdef MVDETR_BWD_TRACE_PLANES
 // tuning aid (never in the shipped build): 100 MHz wall-clock stamps of one workgroup's waves
 __device__ unsigned long long g_bwd_trace[2048];
 extern "C" int mvdetr_debug_bwd_trace(unsigned long long *host, int n)
@@ -469,10 +469,19 @@ static int launch_value_win(hipStream_t st, const float *go, const float *value,
     return (int)hipGetLastError();
 }
 
+// MVDETR_MSDA_BWD_VALUE = tokens (default: msda_bwd_value_tok, token-major windows) | planes (msda_bwd_value_win, for A/B)
+static bool value_planes()
+{
+    static const bool planes = [] { const char *e = getenv("MVDETR_MSDA_BWD_VALUE"); return e && !strcmp(e, "planes"); }();
+    return planes;
+}
+
 int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                              float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits)
 {
+    if (!value_planes())
+        return msda_backward_value_tok(st, go, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, local_hits);
     if (D == 16) return launch_value_win<16, 0>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, nullptr, 0, 0);
     if (D == 32) return launch_value_win<32, 0>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, nullptr, 0, 0);
     return (int)hipErrorInvalidValue;
@@ -483,6 +492,8 @@ int msda_backward_value_tile_fused(hipStream_t st, const float *go, const float 
                                    const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                    const float *stats, int B, int S, int M, int D, int L, float *grad_value)
 {
+    if (!value_planes())
+        return msda_backward_value_tok_fused(st, go, value, shapes, lsi, raw, raw_q, ref, ref_bstride, stats, B, S, M, D, L, grad_value);
     if (D == 16) return launch_value_win<16, 1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr, nullptr, ref, ref_bstride, raw_q);
     return (int)hipErrorNotSupported;
 }

@@ -54,6 +54,13 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
 int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                              float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits);
+// the same through token-major windows (msda_backward_value_tok.hip): what msda_backward_value_tile[_fused] dispatch to
+int msda_backward_value_tok(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                            const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
+                            float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits);
+int msda_backward_value_tok_fused(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                  const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                  const float *stats, int B, int S, int M, int D, int L, float *grad_value);
 // the two halves of the fused training backward (msda_backward_tile.hip, msda_backward_fused.hip)
 int msda_backward_value_tile_fused(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                    const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,

@@ -43,6 +43,37 @@ def encoder_msda_inputs(L, H, W, M=8, D=16, P=4, B=1, seed=0, noise_px=1.0, dtyp
     return value, shapes, level_start_index(shapes), loc.to(dtype).contiguous(), aw.to(dtype)
 
 
+def fused_train_inputs(L, H, W, M=8, D=16, P=4, B=1, seed=0, noise_px=1.0):
+    """The same realistic encoder input in the fused TRAINING pair's form (include/mvdetr_ops.h): -> value, shapes, lsi,
+    reference points [1, L, Lq, 2] (one per (query, level): the query's own cell centre), raw [B, Lq, M*L*P*3] = the
+    module's single GEMM output in the slice-interleaved, level-outermost layout (offsets in pixels = bias grid +
+    N(0, noise_px); logits N(0, 1)), and the row permutation that produced it (slice_major_rows(level_outer=True))."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = torch.as_tensor([(H, W)] * L, dtype=torch.long)
+    S = L * H * W
+    value = torch.randn(B, S, M, D, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    cells = torch.stack([xs / W, ys / H], -1).reshape(-1, 2).repeat(L, 1)           # [S, 2]
+    ref_lm = cells[None, None].expand(1, L, S, 2).contiguous()
+    ang = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+    dirs = torch.stack([ang.cos(), ang.sin()], -1)
+    dirs = dirs / dirs.abs().max(-1, keepdim=True)[0]
+    bias = dirs.view(M, 1, 1, 2) * torch.arange(1, P + 1).view(1, 1, P, 1)          # [M, 1, P, 2]
+    off = bias[None, None] + noise_px * torch.randn(B, S, M, L, P, 2, generator=g)  # reference order (m, l, p, xy)
+    logit = torch.randn(B, S, M, L, P, generator=g)
+    hps, n_off = 32 // D, M * L * P * 2
+    rows = []
+    for l in range(L):                                                              # runs: (level, slice) -> hps heads' offsets, then logits
+        for s_ in range(M // hps):
+            for h in range(hps):
+                rows += [(((s_ * hps + h) * L + l) * P + p) * 2 + xy for p in range(P) for xy in range(2)]
+            for h in range(hps):
+                rows += [n_off + ((s_ * hps + h) * L + l) * P + p for p in range(P)]
+    rows = torch.tensor(rows)
+    plain = torch.cat([off.reshape(B, S, -1), logit.reshape(B, S, -1)], -1)
+    return value, shapes, level_start_index(shapes), ref_lm, plain.index_select(-1, rows).contiguous(), rows
+
+
 def smooth_features(n, c, h, w, seed=0, dtype=torch.float32):
     """O(1) band-limited feature maps (a few low spatial frequencies per channel)."""
     g = torch.Generator().manual_seed(seed)

@@ -38,4 +38,5 @@ if hasattr(lib, "mvdetr_debug_bwd_trace"):
                 continue
             d = lambda a, b: (r[b] - r[a]) / 100 if r[a] and r[b] else float("nan")  # noqa: E731
             print(f"job {j} wave {w}: start {(r[0] - t0) / 100:7.2f}  loads+bounds +{d(0, 1):5.2f}  mass +{d(1, 2):5.2f}  accumulate +{d(2, 3):5.2f}  "
-                  f"bar +{d(3, 4):5.2f}  flush +{d(4, 5):5.2f}")
+                  f"bar +{d(3, 4):5.2f}  flush +{d(4, 5):5.2f}   steps 0-3 (taps | adds): " +
+                  "  ".join(f"{d(6 + 2 * s, 7 + 2 * s):.2f}|{d(7 + 2 * s, 8 + 2 * s):.2f}" for s in range(3)))

@@ -15,7 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 
-from helpers import encoder_msda_inputs, random_msda_inputs  # noqa: E402
+from helpers import encoder_msda_inputs, fused_train_inputs, random_msda_inputs  # noqa: E402
 from mvdetr_amd import geometry  # noqa: E402
 import mvdetr_amd.ops  # noqa: E402,F401
 from mvdetr_amd.ops import warp_perspective  # noqa: E402
@@ -117,18 +117,15 @@ def bench_msda(a, L, H, W, M, D, P, B, S, fwd_bytes, bwd_bytes):
     # fused TRAINING pair: raw [B, Lq, M*L*12] in the level-outer slice layout in, gradient of the same tensor out; the
     # byte counts are SURVEY 8d's for the unfused kernels it replaces (so the fractions compare like for like)
     if not a.skip_bwd and MSDA.fused_train_supported(B, S, M, D, L, S, P):
-        rows = torch.tensor(MSDA.slice_major_rows(M, L, P, D, level_outer=True), device="cuda")
-        plain = torch.cat([off.permute(0, 1, 3, 2, 4, 5).reshape(B, S, -1), logit.permute(0, 1, 3, 2, 4).reshape(B, S, -1)], -1)
-        raw_t = plain.index_select(-1, rows).contiguous()
-        del plain
-        ref_lm = ref[:, :, :, 0, :].permute(0, 2, 1, 3).contiguous()         # [1, L, Lq, 2]
+        del raw, off, logit
+        value, shapes, lsi, ref_lm, raw_t, rows = [x.cuda() for x in fused_train_inputs(L, H, W, M, D, P, B=B, seed=0)]
+        assert rows.tolist() == MSDA.slice_major_rows(M, L, P, D, level_outer=True)
         fn = lambda: MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw_t)  # noqa: E731
         report("msda_fwd_fused_train (+stats)", time_us(fn, a.iters), fwd_bytes)
         out_t, stats_t = fn()
         go = torch.randn(B, S, M * D, device="cuda")
         fn = lambda: MSDA.ms_deform_attn_backward_fused(go, value, shapes, lsi, ref_lm, raw_t, stats_t, out_t)  # noqa: E731
         report("msda_bwd_fused (+memset)", time_us(fn, max(5, a.iters // 3)), bwd_bytes)
-
 
 
 def bench_warp(a, geom, L, C):
