@@ -264,6 +264,12 @@ int mvdetr_msda_last_forward_resources(int *num_regs, int *scratch_bytes_per_lan
  * ...): one name per layout route, asserted by tests/test_warp_gpu.py.  Static storage; never NULL. */
 const char *mvdetr_warp_last_kernel(void);
 
+/* The warp gradient's one-call form keeps its geometry scratch per (device, stream) between calls (hipMallocAsync on the
+ * call's stream, grown on demand).  This drops every cached buffer -- e.g. after destroying streams, or to hand the memory
+ * back; call it when no warp backward is in flight.  Not usable under HIP graph capture: capture the two-step form
+ * (mvdetr_warp_backward_plan_* + mvdetr_warp_perspective_backward_planned_*) with a caller-owned plan buffer instead. */
+int mvdetr_warp_release_scratch(void);
+
 /* Forward kernel variant selection: 0 = auto (default; tiled LDS kernel where it applies, else
  * the gather kernel), 1 = always gather, 2 = tile whenever the shape supports it.  Results are
  * identical up to fp32 summation order; this is a tuning/testing knob.  Returns the previous value.

@@ -945,11 +945,17 @@ static int warp_bwd_impl()
 
 // Scratch of the gather backward, one buffer per (device, stream), grown on demand and kept for the life of the process: every
 // use is enqueued on that stream, so reuse is ordered; calls on different streams get different buffers (thread-safe).
+// Not for HIP graph capture (the allocation would be captured once and the pointer reused across replays): capturing callers
+// use the two-step form (mvdetr_warp_backward_plan_* into their own buffer).  Streams that have been destroyed leave their
+// entry behind; mvdetr_warp_release_scratch() drops every entry (call it when no warp backward is in flight).
+struct WarpScratchEntry { char *ptr; size_t size; };
+static std::mutex g_warp_scratch_mu;
+static std::map<std::pair<int, hipStream_t>, WarpScratchEntry> g_warp_scratch;
 static char *warp_stream_scratch(hipStream_t st, size_t bytes, hipError_t &rc)
 {
-    struct Entry { char *ptr; size_t size; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Entry> cache;
+    using Entry = WarpScratchEntry;
+    std::mutex &mu = g_warp_scratch_mu;
+    auto &cache = g_warp_scratch;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
@@ -1216,6 +1222,22 @@ static int planned_entry(void *stream, const T *grad_dst, const T *M, const void
 
 
 extern "C" {
+
+int mvdetr_warp_release_scratch(void)
+{
+    std::lock_guard<std::mutex> lock(mvdetr::g_warp_scratch_mu);
+    int prev = 0, rc = 0;
+    (void)hipGetDevice(&prev);
+    for (auto &kv : mvdetr::g_warp_scratch) {
+        if (!kv.second.ptr) continue;
+        (void)hipSetDevice(kv.first.first);
+        const hipError_t e = hipFree(kv.second.ptr);           // (synchronises with the device: nothing is still using it)
+        if (e != hipSuccess && !rc) rc = (int)e;
+    }
+    mvdetr::g_warp_scratch.clear();
+    (void)hipSetDevice(prev);
+    return rc;
+}
 
 const char *mvdetr_warp_last_kernel(void) { return mvdetr::g_warp_last_kernel.load(); }
 

@@ -53,8 +53,15 @@ def _transpose(x, n, rows, cols):
 
 
 def last_kernel() -> str:
-    """Name of the device kernel the last warp call on this thread launched (tests / bench introspection)."""
+    """Name of the device kernel the last warp call of this PROCESS launched -- any thread: autograd runs backwards on its
+    own thread (tests / bench introspection)."""
     return _lib.lib().mvdetr_warp_last_kernel().decode()
+
+
+def release_scratch() -> None:
+    """Drop the gather backward's cached geometry scratch of every (device, stream): include/mvdetr_ops.h,
+    mvdetr_warp_release_scratch.  Call when no warp backward is in flight (e.g. after destroying streams)."""
+    _lib.check(_lib.lib().mvdetr_warp_release_scratch(), "mvdetr_warp_release_scratch")
 
 
 def _channel_last_source(src, channels_last_out):

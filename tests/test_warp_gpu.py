@@ -558,3 +558,36 @@ def test_backward_cost_is_bounded_with_the_horizon_in_view(warp):
     y = warp(x.permute(0, 3, 1, 2), Mh, (H, W), channels_last_out=True)
     lhs, rhs = (y.double() * go.double()).sum().item(), (x.double() * g.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2
+
+
+def test_release_scratch_between_backward_calls():
+    """mvdetr_warp_release_scratch: the gather backward keeps its geometry scratch per (device, stream); dropping it
+    between calls changes nothing in the next call's result, on the default stream and on a side stream."""
+    from mvdetr_amd.ops import warp as warp_mod
+    torch.manual_seed(0)
+    N, C, h, w, H, W = 2, 32, 24, 40, 30, 50
+    Mx = _mats(N, h, w, H, W, seed=5) if "_mats" in globals() else None
+    if Mx is None:
+        Mx = torch.eye(3).repeat(N, 1, 1)
+        Mx[:, 0, 0], Mx[:, 1, 1], Mx[:, 0, 2], Mx[:, 1, 2] = 1.2, 1.1, 2.0, -1.5
+    Mx = Mx.cuda().float().contiguous()
+    go = torch.randn(N, H, W, C, device="cuda")
+
+    def run():
+        gs = torch.empty(N, h, w, C, device="cuda")
+        warp_mod._launch("backward", go, Mx, N, C, h, w, H, W, 3, gs)
+        return gs
+
+    a = run()
+    torch.cuda.synchronize()
+    warp_mod.release_scratch()
+    b = run()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c = run()
+    side.synchronize()
+    torch.cuda.synchronize()
+    warp_mod.release_scratch()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert a.abs().max().item() > 0

@@ -35,12 +35,22 @@ def bench_tables(tag):
            f"**`python bench.py`** (`profiles/{tag}_bench.json`): {d['value']} {d['unit']}.", ""]
     out += ["| bench.py key | kernel(s) | avg µs (HIP events) | algorithmic bytes / launch | GB/s | % of 8 TB/s | launches |",
             "|---|---|---|---|---|---|---|"]
-    for key in ("roofline", "roofline_warp", "roofline_warp_bwd", "roofline_msda_bwd"):
+    for key in ("roofline", "roofline_warp", "roofline_warp_bwd", "roofline_msda_bwd", "roofline_train_step"):
         r = d.get(key)
         if not r:
             continue
         out.append(f"| `{key}` | `{r['kernel']}` | {r['avg_launch_us']} | {r['algorithmic_bytes_per_launch']:,} | {r['achieved']:,} | "
                    f"{100 * r['frac']:.1f} | {r['launches_timed']} |")
+    tr = [(key, d[key]) for key in ("roofline", "roofline_warp", "roofline_warp_bwd", "roofline_msda_bwd", "roofline_train_step")
+          if d.get(key) and d[key].get("traffic")]
+    if len(tr) > 1:
+        out += ["", "Memory-side bytes per call (rocprofv3 PMC passes, `" + str(tr[0][1].get("traffic_source")) + "`; (2·FETCH_SIZE + "
+                "WRITE_SIZE)·1024, Infinity-Cache hits included): "
+                + "; ".join(f"`{k}` {r['traffic']:,} = {r['traffic'] / r['algorithmic_bytes_per_launch']:.2f}×" for k, r in tr) + "."]
+    ts = d.get("roofline_train_step")
+    if ts and ts.get("forward_us"):
+        out += ["", f"`roofline_train_step` = fused forward (+ statistics) {ts['forward_us']} µs + fused backward {ts['backward_us']} µs "
+                    f"({100 * ts['backward_frac']:.1f} % of the roofline on the unfused backward's byte count)."]
     r = d.get("roofline", {})
     extra = []
     if r.get("init_weights"):
