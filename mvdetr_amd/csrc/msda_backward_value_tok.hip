@@ -75,9 +75,14 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
     // on different banks
     constexpr int TSTRIDE = 34, TAB = 2 * 4 * TSTRIDE;
     float2 *const table = reinterpret_cast<float2 *>(win64 + NTOK * NPAIR);
-    // (no static LDS: 53,760 B is 42 allocation granules of 1,280 B, three workgroups per CU; 32 more bytes make it two)
-    float (*const red)[4] = reinterpret_cast<float (*)[4]>(mass + NTOK);                     // block reductions of the bound pass
-    static_assert(NTOK * 4 + 32 <= 4 * TAB * 8, "the mass array and the reduction slots live in the tap tables' space");
+    // (no static LDS: 53,760 B is 42 allocation granules of 1,280 B, three workgroups per CU; 32 more bytes make it two.)  The
+    // block reductions' eight slots sit in the two padding entries at the end of the last two runs of wave 3's table -- bytes
+    // no tap entry is ever written to: a wave that leaves the second reduction early starts writing ITS table while a slower
+    // wave still reads the slots (they may not share bytes with any table's entries: a first version had them behind the mass
+    // array, i.e. inside wave 1's table, and one case of the seeded shape sweep failed once in a while)
+    float *const red0 = reinterpret_cast<float *>(table + 3 * TAB + 6 * TSTRIDE + 32);
+    float *const red1 = reinterpret_cast<float *>(table + 3 * TAB + 7 * TSTRIDE + 32);
+    static_assert(NTOK * 4 <= 4 * TAB * 8 && TSTRIDE - 32 >= 2, "the mass array lives in the tap tables' space; two spare entries per run");
     // fixed point: floor(x + 1/2) in one instruction (v_rndne + v_cvt are two; ties are measure zero)
     auto rpi = [](float x) {
         int r;
@@ -168,10 +173,10 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
             b = fmaxf(b, __shfl_xor(b, o, 64));
         }
         __syncthreads();
-        if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = b; }
+        if ((tid & 63) == 0) { red0[tid >> 6] = a; red1[tid >> 6] = b; }
         __syncthreads();
-        a = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-        b = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+        a = fmaxf(fmaxf(red0[0], red0[1]), fmaxf(red0[2], red0[3]));
+        b = fmaxf(fmaxf(red1[0], red1[1]), fmaxf(red1[2], red1[3]));
     };
 
     for (int t = blockIdx.x; t < jobs8 * 8; t += gridDim.x) {
@@ -430,25 +435,28 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
 
                 if (s < 4 && c0 == 0) BTRACE(tr + 7 + 2 * s);
                 // ---- lanes as (cell, corner, pair): one ds_add_u64 per tap of the lane's cell
-                //      (entries read two taps at a time, a batch of 8 taps ahead of the adds that use them: an add must not
-                //      wait for the LDS round trip of its own entry)
+                //      (entries read two taps at a time, a batch ahead of the adds that use them: an add must not wait for the LDS
+                //      round trip of its own entry)
                 if (!direct_only) {
-                    float4 nx[4];
+                    // (2 x 16 bytes = 4 taps per batch: 4, 8 and 16 were measured too -- 8 and 16 spill inside the loop and lose 6 %,
+                    // 4 leaves 16 - 44 bytes of scratch per lane and is 1 - 2 % slower than 2, which has none)
+                    constexpr int RB = 2, NB = CAMS * P / 2 / RB;             // float4 (= 2 taps) per batch, batches per step
+                    float4 nx[RB];
                     auto read_batch = [&](int bt) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) nx[k] = *reinterpret_cast<const float4 *>(my_entries + (bt * 4 + k) * 2);
+                        for (int k = 0; k < RB; ++k) nx[k] = *reinterpret_cast<const float4 *>(my_entries + (bt * RB + k) * 2);
                     };
                     read_batch(0);
 #pragma unroll
-                    for (int bt = 0; bt < CAMS * P / 8; ++bt) {
-                        if (c0 + bt * 2 >= L) break;                            // (uniform)
-                        float4 cu[4];
+                    for (int bt = 0; bt < NB; ++bt) {
+                        if (c0 + bt * RB / 2 >= L) break;                       // (uniform)
+                        float4 cu[RB];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) cu[k] = nx[k];
-                        if (bt + 1 < CAMS * P / 8) read_batch(bt + 1);
+                        for (int k = 0; k < RB; ++k) cu[k] = nx[k];
+                        if (bt + 1 < NB) read_batch(bt + 1);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int cam = bt * 2 + k / 2;
+                        for (int k = 0; k < RB; ++k) {
+                            const int cam = (bt * RB + k) / 2;
                             if (c0 + cam >= L) break;                           // (uniform)
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {

@@ -634,7 +634,7 @@ def test_fused_query_levels_rejects_inconsistent_ranges(ops):
 
 
 # ---- grad_value through fixed-point LDS windows (msda_backward_tile.hip) ------------------------------------
-@pytest.mark.parametrize("variant", ["plain", "tiny", "huge", "wild_weights", "d32", "mixed_magnitudes"])
+@pytest.mark.parametrize("variant", ["plain", "tiny", "huge", "wild_weights", "d32", "mixed_magnitudes", "converging", "far_mix"])
 def test_backward_fixed_point_windows_keep_fp32_accuracy(ops, variant):
     """The encoder-shaped backward accumulates grad_value in per-tile fixed-point windows whose scale follows
     the data: the error stays far below the 1e-4 bar relative to the gradient's own scale for tiny, huge,
@@ -651,6 +651,17 @@ def test_backward_fixed_point_windows_keep_fp32_accuracy(ops, variant):
         aw = (aw - 0.02) * 300.0                                   # negative and far from a softmax
     elif variant == "mixed_magnitudes":
         go = go * torch.logspace(-6, 3, go.shape[1]).view(1, -1, 1)        # 9 decades across the queries
+    elif variant == "converging":
+        # the mass bound's worst case (msda_bwd_value_tok: one atomic per tap + 2 x 2 dilation): every tap of every query of a
+        # tile row lands on (almost) the same token, with weights far above a softmax's -- no accumulator may overflow
+        H_, W_ = 19, 37
+        target = torch.tensor([17.3 / W_, 9.6 / H_])
+        loc = target.expand_as(loc).clone() + 1e-4 * torch.randn(loc.shape, generator=torch.Generator().manual_seed(9))
+        aw = aw * 40.0
+    elif variant == "far_mix":
+        # a fifth of the taps far outside every window (direct fp32 atomics) among near ones, some outside the map
+        far = torch.rand(loc.shape[:-1], generator=torch.Generator().manual_seed(10)) < 0.2
+        loc = torch.where(far[..., None], torch.rand(loc.shape, generator=torch.Generator().manual_seed(11)) * 1.4 - 0.2, loc)
     ref = c_oracle.msda_backward(value.double(), shapes, lsi, loc.double(), aw.double(), go.double())[0]
     gv = MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), 64)[0].cpu().double()
     assert torch.isfinite(gv).all()
