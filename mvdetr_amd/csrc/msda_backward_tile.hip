@@ -480,7 +480,9 @@ int msda_backward_value_tile(hipStream_t st, const float *go, const float *value
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                              float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits)
 {
-    if (!value_planes())
+    // msda_bwd_value_tok addresses one batch element's tensors with 32-bit byte offsets: larger ones keep the 64-bit kernel
+    const int64_t lim = (int64_t)1 << 32;
+    if (!value_planes() && (int64_t)S * M * L * TILE_P * 2 * 4 < lim && (int64_t)S * M * D * 4 < lim)
         return msda_backward_value_tok(st, go, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, local_hits);
     if (D == 16) return launch_value_win<16, 0>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, nullptr, 0, 0);
     if (D == 32) return launch_value_win<32, 0>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, nullptr, 0, 0);
@@ -492,7 +494,8 @@ int msda_backward_value_tile_fused(hipStream_t st, const float *go, const float 
                                    const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                    const float *stats, int B, int S, int M, int D, int L, float *grad_value)
 {
-    if (!value_planes())
+    const int64_t lim = (int64_t)1 << 32;
+    if (!value_planes() && (int64_t)S * raw_q * 4 < lim && (int64_t)S * M * D * 4 < lim)
         return msda_backward_value_tok_fused(st, go, value, shapes, lsi, raw, raw_q, ref, ref_bstride, stats, B, S, M, D, L, grad_value);
     if (D == 16) return launch_value_win<16, 1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr, nullptr, ref, ref_bstride, raw_q);
     return (int)hipErrorNotSupported;
