@@ -319,28 +319,26 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
             float2 ng[CAMS];
             unsigned n_gofs = 0;                              // of the tap lane's (cell, camera) row, for the far path
             bool n_valid = false;
-            auto request = [&](int j) {
-                {   // lanes as taps: this lane's tap
-                    const int x_ = X0 + 2 * j + pc;
-                    n_valid = row_ok && x_ < Wq && tap_cam_ok;
-                    const unsigned q = n_valid ? tap_q + (unsigned)(wy_row * Wq + x_) : 0u;      // inside the batch element
-                    n_gofs = q * row_b;
-                    nraw.o = *reinterpret_cast<const float2 *>(loc_b + (q * loc_q + loc_c));
-                    nraw.w = *reinterpret_cast<const float *>(aw_b + (q * aw_q + aw_c));
-                    if constexpr (FUSED) {
-                        nraw.r = *reinterpret_cast<const float2 *>(ref_b + q * 8u);
-                        nraw.st = *reinterpret_cast<const float2 *>(st_b + q * (unsigned)(M * 8));
-                    } else {
-                        nraw.r = nraw.st = make_float2(0.f, 0.f);
-                    }
+            auto request_taps = [&](int j, TapRaw &t, bool &ok, unsigned &gofs) {      // lanes as taps: this lane's tap
+                const int x_ = X0 + 2 * j + pc;
+                ok = row_ok && x_ < Wq && tap_cam_ok;
+                const unsigned q = ok ? tap_q + (unsigned)(wy_row * Wq + x_) : 0u;            // inside the batch element
+                gofs = q * row_b;
+                t.o = *reinterpret_cast<const float2 *>(loc_b + (q * loc_q + loc_c));
+                t.w = *reinterpret_cast<const float *>(aw_b + (q * aw_q + aw_c));
+                if constexpr (FUSED) {
+                    t.r = *reinterpret_cast<const float2 *>(ref_b + q * 8u);
+                    t.st = *reinterpret_cast<const float2 *>(st_b + q * (unsigned)(M * 8));
+                } else {
+                    t.r = t.st = make_float2(0.f, 0.f);
                 }
-                {   // lanes as (cell, corner, pair): grad_out pairs of the cell's cameras
-                    const int x_ = X0 + 2 * j + ct;
-                    const unsigned cellq = row_ok && x_ < Wq ? (unsigned)(wy_row * Wq + x_) : 0u;
-                    const unsigned o = cellq * row_b + (unsigned)pair * 8u;
+            };
+            auto request_g = [&](int j) {        // lanes as (cell, corner, pair): grad_out pairs of the cell's cameras
+                const int x_ = X0 + 2 * j + ct;
+                const unsigned cellq = row_ok && x_ < Wq ? (unsigned)(wy_row * Wq + x_) : 0u;
+                const unsigned o = cellq * row_b + (unsigned)pair * 8u;
 #pragma unroll
-                    for (int k = 0; k < CAMS; ++k) ng[k] = *reinterpret_cast<const float2 *>(go_b + (cam_q[k] * row_b + o));
-                }
+                for (int k = 0; k < CAMS; ++k) ng[k] = *reinterpret_cast<const float2 *>(go_b + (cam_q[k] * row_b + o));
             };
         float scale = 0.f, inv_scale = 0.f;
         if (!direct_only) {
@@ -400,7 +398,8 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
             // (requesting the first pair before the mass bound, and batching the bound pass's grad_out loads, were both
             // measured SLOWER: 690 - 725 us against 671 for the whole backward -- tools/gpu_r4o.sh)
             set_chunk(c0);
-            request(0);
+            request_taps(0, nraw, n_valid, n_gofs);
+            request_g(0);
             for (int s = 0; s < steps; ++s) {
                 const TapRaw raw_ = nraw;
                 float2 g[CAMS];
@@ -408,7 +407,11 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
                 for (int k = 0; k < CAMS; ++k) g[k] = ng[k];
                 const bool valid = n_valid;
                 const unsigned my_gofs = n_gofs;
-                if (s + 1 < steps) request(s + 1);
+                // (requesting the tap data TWO steps ahead was measured too: 685 - 690 us against 662 - 677 for the whole backward)
+                if (s + 1 < steps) {
+                    request_taps(s + 1, nraw, n_valid, n_gofs);
+                    request_g(s + 1);
+                }
 
                 if (s < 4 && c0 == 0) BTRACE(tr + 6 + 2 * s);
                 // ---- lanes as taps: the four (weight, record) entries of this lane's tap
