@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
         {
             for (int c0 = 0; c0 < L; c0 += CAMS) {
             // (requesting the first pair before the mass bound, and batching the bound pass's grad_out loads, were both
-            // measured SLOWER: 690 - 725 us against 671 for the whole backward -- tools/gpu_r4o.sh)
+            // measured SLOWER: 690 - 725 us against 671 for the whole backward -- DESIGN 4.3d)
             set_chunk(c0);
             request_taps(0, nraw, n_valid, n_gofs);
             request_g(0);

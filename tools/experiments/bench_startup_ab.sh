@@ -1,6 +1,6 @@
 #!/bin/bash
 # r04 re-baseline: all GPU tests, MIOpen find-mode A/B of the bench start-up (separate user-db / cache dirs), microbench
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; cd $R; mkdir -p $O
 ( time python -m pytest tests -m gpu -x -q 2>&1 | tail -6 ) 2>&1 | tee $O/alltests.txt
 for mode in 2 default; do
   export MIOPEN_USER_DB_PATH=/tmp/miopen_db_$mode MIOPEN_CUSTOM_CACHE_DIR=/tmp/miopen_cache_$mode

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; cd $R; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; cd $R; mkdir -p $O
 for v in tokens planes tokens; do
 echo "== $v"; MVDETR_MSDA_BWD_VALUE=$v python tools/microbench.py --iters 20 --only msda 2>&1 | grep -v amdgpu.ids | grep "bwd" 
 done | tee $O/microbench_r4l.txt
