@@ -25,6 +25,7 @@ __device__ __forceinline__ unsigned hash(unsigned a, unsigned b)
 // MODE 3: 8 taps x 8 pairs (one corner per instruction), token-major, random taps (u64)
 // MODE 4: 1 tap x 4 corners x 16 channels, u32, token-major 64 B per token, WW = 46 (1 pass)
 // MODE 5: MODE 1 + the per-instruction LDS read of (weight, address) and the fixed-point packing VALU work
+// MODE 6 / 7: fp32 atomics (ds_add_f32; build with -munsafe-fp-atomics), MODE 4's addresses; 7 adds the entry read + multiply
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, int iters)
 {
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
             addr[u] = (int)(h % NTOK) * 8 + (lane & 7);
         } else {
             const int corner = lane >> 4, ch = lane & 15;
+            slot[u] = (u * 4 + wave) * 8 + corner;
             const unsigned h = hash(wv, u);
             const int x0 = (int)(h % (WW - 1)), y0 = (int)((h >> 10) % (WH - 1));
             addr[u] = ((y0 + (corner >> 1)) * WW + x0 + (corner & 1)) * 16 + ch;
@@ -73,7 +75,12 @@ __global__ __launch_bounds__(256) void k(float *out, int iters)
                 const int lo = __float2int_rn(a), hi = __float2int_rn(b) + (lo >> 31);
                 v = (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
             }
-            if (MODE == 4)
+            if (MODE == 6 || MODE == 7) {
+                // fp32 atomics (needs -munsafe-fp-atomics for the native ds_add_f32; without it hipcc emits a CAS loop)
+                float fv = g0;
+                if (MODE == 7) fv = tapinfo[slot[u]].x * g0;
+                __hip_atomic_fetch_add(reinterpret_cast<float *>(win64) + addr[u], fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (MODE == 4)
                 __hip_atomic_fetch_add(reinterpret_cast<int *>(win64) + addr[u], (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else
                 __hip_atomic_fetch_add(&win64[addr[u]], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -114,6 +121,8 @@ int main()
         run<3>("u64 8 taps x 8 pairs (one corner), token-major", d_out, w);
         run<4>("u32 1 tap x 4 corners x 16 channels, token-major, WW=46", d_out, w);
         run<5>("u64 2 taps x 4 x 8, WW=46 + tapinfo read + fixed-point packing", d_out, w);
+        run<6>("f32 1 tap x 4 corners x 16 channels, token-major (ds_add_f32)", d_out, w);
+        run<7>("f32 1 tap x 4 x 16 + tapinfo read + multiply", d_out, w);
     }
     return 0;
 }
