@@ -56,6 +56,10 @@ def bench_tables(tag):
     if r.get("init_weights"):
         extra.append(f"`roofline` with the reference's zero offset weights: {r['init_weights']['avg_launch_us']} µs, "
                      f"{100 * r['init_weights']['frac']:.1f} %")
+    if r.get("uncalibrated_offsets"):
+        u = r["uncalibrated_offsets"]
+        extra.append(f"`roofline` with the perturbation as rounds 2 – 4 quoted it (offset spreads {u['offset_std_px_per_layer']} px per layer instead of "
+                     f"the calibrated 1 px; like for like with `BENCH_r03`): {u['avg_launch_us']} µs, {100 * u['frac']:.1f} %")
     if r.get("traffic"):
         extra.append(f"memory-side bytes per launch (PMC, `{r.get('traffic_source')}`): {r['traffic']:,} = "
                      f"{r['traffic'] / r['algorithmic_bytes_per_launch']:.2f}× the algorithmic bytes")

@@ -106,7 +106,7 @@ def bench_msda(a, L, H, W, M, D, P, B, S, fwd_bytes, bwd_bytes):
     value, shapes, lsi = [x.cuda() for x in encoder_msda_inputs(L, H, W, M, D, P, B=B, seed=0)[:3]]
     fn = lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, ref, off, logit, level_major=True)  # noqa: E731
     report("msda_fwd_fused[all levels]", time_us(fn, a.iters), fwd_bytes)
-    for n_own in (1, 2):
+    for n_own in (1, 2) if B == 1 else ():          # (a rank's share is a slice of the query axis: dense only for one frame)
         q = n_own * H * W
         own_bytes = 4 * B * (S * M * D + 3 * q * M * L * P + q * M * D)
         o2, l2, r2 = off[:, :q], logit[:, :q], ref[:, :q]
