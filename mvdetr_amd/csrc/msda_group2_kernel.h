@@ -229,12 +229,14 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
             }
             if constexpr (FUSED == 0) {
                 // Public contract, `auto`: the sample also says whether this tile's taps are near their cells at all.  If
-                // fewer than half are, windows would be wasted on it: the job computes its outputs in the gather formulation
+                // fewer than a QUARTER are, windows would be wasted on it (half, the first version's test, sent jobs to the gather
+                // body at a spread of 4 px where the windows still win: 749 vs 533 us for the whole call; a third does the same at 6 px:
+                // 833 vs 715; with a quarter the worst point of the sweep is 9 px, 908 us against the gather kernel's 722): the job computes its outputs in the gather formulation
                 // instead (every wave sees the same sample and takes the same way; this replaces round 3's separate probe
                 // kernel, its scratch allocation and two launch gaps in front of every forward).
                 const float tl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sloc)));
                 const float tc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scnt)));
-                if ((opts & GROUP_OPT_STANDDOWN) && tl * 2.f < tc) {
+                if ((opts & GROUP_OPT_STANDDOWN) && tl * 4.f < tc) {
                     // items of the job: (camera, cell of the tile, 16-byte chunk of the slice); GU per lane and iteration,
                     // branch-free, so that their loads are in flight together
                     constexpr int CH = SLICE / 4, NIT = NG * TH * TW * CH, T = Cfg::THREADS, GU = 4;
@@ -457,10 +459,17 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
                 // taps that left the window: straight from global memory (zero padding by test)
                 for (int l = 0; l < L; ++l) {
                     unsigned mm = (ms_lane[l * NCL] >> (c * P)) & 15u;
+                    if (!mm) continue;
+                    // the (query, level)'s four points in ONE round trip (16-byte loads, as the stream took them), not one per
+                    // missed tap in front of its gathers
+                    const float4 la4 = *reinterpret_cast<const float4 *>(lp + l * lay.l_l), lb4 = *reinterpret_cast<const float4 *>(lp + l * lay.l_l + 4);
+                    const float4 wa4 = *reinterpret_cast<const float4 *>(wp + l * lay.l_w);
                     while (mm) {
                         const int pp = __ffs((int)mm) - 1;
                         mm &= mm - 1;
-                        float lx = lp[l * lay.l_l + pp * 2 + 0], ly = lp[l * lay.l_l + pp * 2 + 1], a = wp[l * lay.l_w + pp];
+                        float lx = pp == 0 ? la4.x : pp == 1 ? la4.z : pp == 2 ? lb4.x : lb4.z;
+                        float ly = pp == 0 ? la4.y : pp == 1 ? la4.w : pp == 2 ? lb4.y : lb4.w;
+                        float a = pp == 0 ? wa4.x : pp == 1 ? wa4.y : pp == 2 ? wa4.z : wa4.w;
                         if constexpr (FUSED) {
                             const int ri = l * lay.r_l + (FUSED == 2 ? 0 : pp * 2);
                             lx = rp[ri + 0] + lx * (1.f / fW);
