@@ -104,7 +104,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
+    if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
     if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
 
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
+    if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
     if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
 
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
+    if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
     if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
 
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) equal = false;
+    if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) equal = false;
     if (FUSED && !equal) {
         // (the fused entry's callers promise equal level shapes: make the misuse loud)
         for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < (int64_t)B * S * M * D; i += (int64_t)gridDim.x * THREADS)

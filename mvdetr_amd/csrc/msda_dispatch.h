@@ -76,6 +76,11 @@ int msda_backward_fused_sampling(hipStream_t st, const float *go, const float *v
 //                         far points of the ray; the LDS-tiled backward kernels shift their windows by msda_probe_shift().
 #define MSDA_PROBE_SAMPLES 16384
 #define MSDA_PROBE_RADIUS 5.5f
+// a call stands down to the generic formulation when fewer than 1 / MSDA_PROBE_NEAR_DIV of the sampled taps are near (round 4's
+// noise sweep: with a half, the backward left the windows at a spread of 6 px, 3.08 ms where they take 1.93; a quarter keeps them)
+#ifndef MSDA_PROBE_NEAR_DIV
+#define MSDA_PROBE_NEAR_DIV 4
+#endif
 #define MSDA_PROBE_MAXHEADS 64
 #define MSDA_PROBE_INTS (1 + 3 * MSDA_PROBE_MAXHEADS)
 #define MSDA_PROBE_MAXSHIFT 3

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
     extern __shared__ __attribute__((aligned(16))) float win[];
     if constexpr (FUSED == 0) {
         // the locality probe found the taps far from their queries: windows would be wasted, gather instead
-        if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) {
+        if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) {
             msda_fwd_gather_body<float, 4>((int64_t)blockIdx.x * Cfg::THREADS + threadIdx.x, (int64_t)gridDim.x * Cfg::THREADS,
                                            value, shapes, lsi, loc, aw, B, S, M, Cfg::D, L, S, TILE_P, out);
             return;

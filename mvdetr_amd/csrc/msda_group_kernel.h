@@ -69,7 +69,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     GROUP_STAMP(0);
     if constexpr (FUSED == 0) {
         // the locality probe found the taps far from their queries: windows would be wasted, gather instead
-        if (local_hits && *local_hits * 2 < MSDA_PROBE_SAMPLES) {
+        if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) {
             msda_fwd_gather_body<float, 4>((int64_t)blockIdx.x * Cfg::THREADS + threadIdx.x, (int64_t)gridDim.x * Cfg::THREADS,
                                            value, shapes, lsi, off, logit, B, S, M, Cfg::D, NG, S, TILE_P, out);
             return;
