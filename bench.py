@@ -453,32 +453,40 @@ def main():
         frames_per_step, scaling = world * Bf, "weak"
 
     # the synthetic "learned" offsets are defined by their spread in pixels: calibrate it on this model's own
-    # queries, layer by layer (every rank does the same, deterministically; a view-sharded step has collectives in it, so
-    # there the calibration runs on the unsharded model of each rank)
+    # queries, layer by layer -- on ONE fixed seeded frame, so that every rank arrives at the same projections (a view-sharded
+    # step has collectives in it: the calibration always runs the unsharded model of the rank)
     clock.mark("model_and_inputs")
     offset_calibration, uncalibrated = None, None
-    if offset_std and attn_layers:
-        cal_imgs = imgs if not (a.parallel == "views" and world > 1) else torch.randn(1, N, 3, Hi, Wi, generator=torch.Generator().manual_seed(1000)).to(dev)
+
+    def calibrate():
+        nonlocal offset_calibration, uncalibrated
+        if not (offset_std and attn_layers):
+            return
+        cal_imgs = torch.randn(1, N, 3, Hi, Wi, generator=torch.Generator().manual_seed(1000)).to(dev)
+        cal_M = M[:1]
 
         def cal_run():
             with torch.no_grad():
-                model(cal_imgs[:1], M[:1])
+                model(cal_imgs, cal_M)
         uncalibrated = [(at.sampling_offsets.weight.detach().clone(), at.attention_weights.weight.detach().clone()) for at in attn_layers]
         offset_calibration = calibrate_sampling(attn_layers, cal_run, offset_std)
-        del cal_imgs
-        clock.mark("offset_calibration_incl_miopen_find")     # (the first frames of the process run here)
 
     tuning_shared = None
-    if world > 1 and gemm_tuning and a.parallel == "dp":
+    rank0_first = world > 1 and gemm_tuning and a.parallel == "dp"
+    if not rank0_first:
+        calibrate()
+        clock.mark("offset_calibration_incl_miopen_find")     # (the first frames of the process run here)
+    else:
         # (dp only: a view-sharded step has collectives in it, rank 0 cannot run it alone)
-        # rank 0 warms up first: TunableOp's measured GEMM picks go to ONE results file and MIOpen's find results to its
-        # user database; the other ranks then read both instead of each spending its warm-up measuring the same shapes.
-        # Every rank runs the same barrier sequence whatever fails in between.
+        # rank 0 goes first -- calibration frames and warm-up steps: TunableOp's measured GEMM picks go to ONE results file and
+        # MIOpen's find results to its user database; the other ranks then read both instead of each spending minutes
+        # measuring the same shapes at the same time.  Every rank runs the same barrier sequence whatever fails in between.
         tun = torch.cuda.tunable
         shared = os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_shared_{os.environ.get('MASTER_PORT', '0')}.csv")
         tuning_shared = True
         if rank == 0:
             try:
+                calibrate()
                 for _ in range(max(a.warmup, 1)):
                     step()
                 torch.cuda.synchronize()
@@ -495,6 +503,10 @@ def main():
             except Exception as ex:                # pragma: no cover
                 tuning_shared = False
                 print(f"[bench] rank {rank}: reading the shared TunableOp results failed ({ex}); tuning here", file=sys.stderr)
+            calibrate()
+        elif offset_calibration is None:
+            calibrate()                            # (rank 0's first attempt failed before the calibration)
+        clock.mark("offset_calibration_incl_miopen_find")
     clock.mark("gemm_tuning_share")
     for i in range(a.warmup):
         step()
