@@ -21,7 +21,7 @@ Prints ONE JSON line (rank 0):
                    here with HIP events on the launching stream, against the 8 TB/s HBM peak;
                    `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes
                    (profiles/*_traffic.json), null when that file is absent
-  roofline_warp / roofline_warp_bwd / roofline_msda_bwd / roofline_train_step
+  roofline_warp / roofline_warp_bwd / roofline_msda_bwd / roofline_train_step / roofline_iid_offsets
                    the other kernels SURVEY 8d names, same accounting (4*N*C*(h*w + H*W) bytes for the warp and its
                    gradient; 4*(Lq*M*D + 2*S*M*D + 6*Lq*M*L*P) for the MSDA backward), HIP events over 12 launches each,
                    measured on rank 0 after the timed region; roofline.code_object = registers / scratch (spill) bytes per
@@ -269,6 +269,14 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
             value, shapes, lsi, ref_lm, raw, _ = [x.to(feat.device) for x in fused_train_inputs(N, hh, ww, M_, D_, 4, seed=0)]
             gout = torch.randn(1, S, M_ * D_, device=feat.device)
             fbytes = 4 * (S * M_ * D_ + 3 * S * M_ * N * 4 + S * M_ * D_)
+            # the inference kernel on the same iid input (SURVEY 8d's MICROBENCHMARK definition: every tap's offset drawn
+            # independently; in the model the learned part of an offset is a linear function of the query, so neighbouring
+            # queries' taps move together and the LDS reads conflict less -- `roofline` is the in-model figure)
+            us_i, mn_i = time_launches(lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, ref_lm, None, None, raw=raw,
+                                                                                 ref_level_major=True, raw_level_outer=True), launches)
+            out["roofline_iid_offsets"] = roofline_entry(
+                MSDA.last_forward_kernel(), us_i, mn_i, fbytes, launches,
+                "mvdetr_msda_forward_fused_f32 on SURVEY 8d's microbenchmark input: bias grid + iid N(0, 1 px) per tap, logits N(0, 1)")
             o_, st_ = MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw)
             us_f, mn_f = time_launches(lambda: MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw), launches)
             us_b, mn_b = time_launches(lambda: MSDA.ms_deform_attn_backward_fused(gout, value, shapes, lsi, ref_lm, raw, st_, o_), launches)

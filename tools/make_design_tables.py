@@ -35,7 +35,7 @@ def bench_tables(tag):
            f"**`python bench.py`** (`profiles/{tag}_bench.json`): {d['value']} {d['unit']}.", ""]
     out += ["| bench.py key | kernel(s) | avg µs (HIP events) | algorithmic bytes / launch | GB/s | % of 8 TB/s | launches |",
             "|---|---|---|---|---|---|---|"]
-    for key in ("roofline", "roofline_warp", "roofline_warp_bwd", "roofline_msda_bwd", "roofline_train_step"):
+    for key in ("roofline", "roofline_iid_offsets", "roofline_warp", "roofline_warp_bwd", "roofline_msda_bwd", "roofline_train_step"):
         r = d.get(key)
         if not r:
             continue
