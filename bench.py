@@ -244,6 +244,15 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
             warp_mod.last_kernel(), us, mn, wbytes, launches,
             "gradient of the warp w.r.t. the features, channel-last on both sides (C ABI entry: candidate scans + gather + "
             "stragglers; deterministic, no atomics)")
+        # what a training loop without augmentation runs in steady state: the autograd function keeps the gradient's geometry
+        # ("plan": candidate scans, heavy-block and odd-pixel lists) per matrix tensor, so only the gather is launched
+        plan = warp_mod._plans.get(pm, (N, C, h, w, H, W))
+        us_p, mn_p = time_launches(lambda: warp_mod._launch("backward", go, pm, N, C, h, w, H, W, 3, gs, plan=plan), launches)
+        out["roofline_warp_bwd"]["planned"] = {
+            "kernel": warp_mod.last_kernel(), "avg_launch_us": round(us_p, 2), "min_launch_us": round(mn_p, 2),
+            "frac": round(wbytes / (us_p * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+            "what": "mvdetr_warp_perspective_backward_planned_f32 with the plan of mvdetr_warp_backward_plan_f32 reused (what "
+                    "WarpPerspectiveFunction.backward does while the matrices do not change)"}
         del go, gs
         # MSDA backward at this configuration's encoder shape, SURVEY 8d's input (bias grid + N(0, 1 px) offsets)
         wf = model.world_feat

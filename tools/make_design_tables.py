@@ -70,6 +70,10 @@ def bench_tables(tag):
     w = d.get("roofline_warp", {}).get("nchw_to_nchw")
     if w:
         extra.append(f"warp in the literal kornia layouts (NCHW → NCHW, `{w['kernel']}`): {w['avg_launch_us']} µs, {100 * w['frac']:.1f} %")
+    wp = d.get("roofline_warp_bwd", {}).get("planned")
+    if wp:
+        extra.append(f"warp gradient with its geometry plan reused (`{wp['kernel']}` alone, the steady state of training without "
+                     f"augmentation): {wp['avg_launch_us']} µs, {100 * wp['frac']:.1f} %")
     if extra:
         out += ["", "; ".join(extra) + "."]
     return out
