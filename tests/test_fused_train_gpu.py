@@ -198,3 +198,48 @@ def test_fused_training_pair_at_wildtrack_size(ops):
     rhs = (gv.cpu().double() * value.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0) + 1e-2
     assert math.isfinite(lhs)
+
+
+def _fused_sweep_cases(n=8, seed=77):
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    for i in range(n):
+        L = rnd.choice([6, 7])
+        H, W = rnd.randint(1, 30), rnd.randint(1, 70)
+        B = rnd.choice([1, 1, 2])
+        noise = rnd.choice([0.0, 1.0, 3.0, 8.0])                  # 8 px: most taps leave their windows (the far paths)
+        cases.append((i, L, H, W, B, noise))
+    return cases
+
+
+@pytest.mark.parametrize("i,L,H,W,B,noise", _fused_sweep_cases())
+def test_fused_training_pair_seeded_sweep(ops, i, L, H, W, B, noise):
+    """Random geometry (partial tiles, single rows / columns, two frames, offsets from 0 to 8 px) through the fused training pair
+    against the fp64 chain; the regression form of tools/fuzz_parity.py's fused leg."""
+    MSDA = ops
+    M, D = 8, 16
+    value, shapes, lsi, ref_ql, off, logit = _raw_inputs(L, H, W, M, D, B, seed=200 + i, noise_px=noise)
+    S = value.shape[1]
+    if not MSDA.fused_train_supported(B, S, M, D, L, S, 4):
+        pytest.skip("shape outside the fused pair")
+    raw, rows = _to_raw(MSDA, off, logit, M, L, D)
+    ref_lm = ref_ql.transpose(0, 1).contiguous()[None]
+    dv = dict(value=value.cuda(), shapes=shapes.cuda(), lsi=lsi.cuda(), ref=ref_lm.cuda(), raw=raw.cuda())
+    out, stats = MSDA.ms_deform_attn_forward_fused_train(dv["value"], dv["shapes"], dv["lsi"], dv["ref"], dv["raw"])
+    go = torch.randn(B, S, M * D, generator=torch.Generator().manual_seed(300 + i))
+    gv_ref, goff_ref, glogit_ref, loc, aw = _reference_grads(value, shapes, lsi, ref_ql, off, logit, go)
+    want_out = c_oracle.msda_forward(value.double(), shapes, lsi, loc.contiguous(), aw.contiguous())
+    assert (out.cpu().double() - want_out).abs().max().item() < 1e-4
+    gv, graw = MSDA.ms_deform_attn_backward_fused(go.cuda(), dv["value"], dv["shapes"], dv["lsi"], dv["ref"], dv["raw"], stats, out)
+    inv = torch.empty_like(rows)
+    inv[rows] = torch.arange(rows.numel())
+    gplain = graw.cpu().double().index_select(-1, inv)
+    n_off = M * L * 4 * 2
+    goff, glogit = gplain[..., :n_off].reshape(goff_ref.shape), gplain[..., n_off:].reshape(glogit_ref.shape)
+    assert ((gv.cpu().double() - gv_ref).abs() / (1.0 + gv_ref.abs())).max().item() < 2e-4, "grad_value"
+    px = loc * torch.tensor([W, H], dtype=torch.float64) - 0.5
+    smooth = ((px - px.round()).abs().amin(-1) > 1e-4).double()
+    assert ((goff - goff_ref).abs() / (1.0 + goff_ref.abs()) * smooth[..., None]).max().item() < 2e-4, "grad of the raw offsets"
+    # (a logit's gradient is a * (d a - D) with d a a blend of <grad_out, value> dots of magnitude ~4: error against that scale)
+    assert ((glogit - glogit_ref).abs() / (4.0 + glogit_ref.abs())).max().item() < 2e-4, "grad of the raw logits"
