@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 10
+#define MVDETR_OPS_ABI_VERSION 11   /* 11: + mvdetr_warp_release_scratch */
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # MVDETR_OPS_LIB: another build of the same sources (the phase-stamp build libmvdetr_ops_trace.so of tools/experiments)
 LIB_PATH = os.environ.get("MVDETR_OPS_LIB") or os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
