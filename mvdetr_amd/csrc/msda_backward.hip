@@ -122,10 +122,27 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
         static const bool tile_ok = [] { const char *e = getenv("MVDETR_MSDA_BWD_IMPL"); return !(e && !strcmp(e, "atomic")); }();
         const bool all16 = a16 && aligned(loc, 16) && aligned(aw, 16) && aligned(grad_value, 16) && aligned(grad_loc, 16) &&
                            aligned(grad_aw, 16);
-        if (tile_ok && msda_tile_supported(B, S, M, D, L, Lq, P, all16, 0, L)) {
-            // a stream-ordered scratch int carries the locality probe's verdict to both kernels: calls whose taps are
-            // far from their queries (e.g. uniformly random locations) run the lane-group backward inside the first
-            // launch instead -- no host synchronisation, no dependence on the caller's allocator
+        // MVDETR_MSDA_BWD_IMPL = split (default: grad_value from msda_bwd_onepass<DOTS = 0>, the sampling gradients from
+        // msda_bwd_sampling_*) | onepass (all three gradients from ONE kernel, msda_backward_onepass.hip) | twopass (rounds 2-4:
+        // msda_bwd_value_tok + msda_bwd_sampling_*) | atomic (the generic kernel)
+        static const int impl = [] {
+            const char *e = getenv("MVDETR_MSDA_BWD_IMPL");
+            return !e ? 0 : !strcmp(e, "onepass") ? 1 : !strcmp(e, "twopass") ? 2 : 0;
+        }();
+        const bool tile_shapes = tile_ok && msda_tile_supported(B, S, M, D, L, Lq, P, all16, 0, L);
+        const bool op_ok = tile_shapes && msda_backward_onepass_supported(B, S, M, D, L, (int64_t)M * L * P * 2);
+        if (op_ok && impl == 1)
+            return msda_backward_onepass(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, true);
+        if (op_ok && impl == 0) {
+            // no probe, no scratch: both kernels take the window shift and the stand-down decision from their jobs' own samples
+            int rc = msda_backward_scatter(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, true);
+            if (!rc) rc = msda_backward_sampling_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_loc, grad_aw, nullptr);
+            return rc;
+        }
+        if (tile_shapes) {
+            // rounds 2-4's pair (and 32-channel heads): a stream-ordered scratch int carries the locality probe's verdict to both
+            // kernels: calls whose taps are far from their queries (e.g. uniformly random locations) run the lane-group
+            // backward inside the first launch instead -- no host synchronisation
             int *hits = nullptr;
             if (hipMallocAsync(reinterpret_cast<void **>(&hits), MSDA_PROBE_INTS * sizeof(int), st) != hipSuccess) hits = nullptr;
             int rc = hits ? msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits) : 0;
@@ -207,6 +224,9 @@ int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const
         channels != 16)
         return (int)hipErrorNotSupported;
     if (raw_query_stride < num_heads * num_levels * num_point * 3 || raw_query_stride % 4) return (int)hipErrorInvalidValue;
+    // the kernels address one batch element's raw tensor (and its gradient) with 32-bit offsets of the CALLER's query stride,
+    // which may be wider than the dense width mvdetr_msda_fused_train_supported() bounds (a column block of a wider GEMM)
+    if ((int64_t)spatial_size * raw_query_stride >= ((int64_t)1 << 29)) return (int)hipErrorNotSupported;
     const uintptr_t al = reinterpret_cast<uintptr_t>(grad_output) | reinterpret_cast<uintptr_t>(value) |
                          reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(out) |
                          reinterpret_cast<uintptr_t>(grad_value) | reinterpret_cast<uintptr_t>(grad_raw);
@@ -214,9 +234,22 @@ int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const
         (ref_batch_stride & 1))
         return (int)hipErrorNotSupported;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc = msda_backward_value_tile_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
-                                            reference_points, ref_batch_stride, stats, batch, spatial_size, num_heads,
-                                            channels, num_levels, grad_value);
+    static const int impl = [] {
+        const char *e = getenv("MVDETR_MSDA_BWD_IMPL");
+        return !e ? 0 : !strcmp(e, "onepass") ? 1 : !strcmp(e, "twopass") ? 2 : 0;
+    }();
+    const bool op_ok = msda_backward_onepass_supported(batch, spatial_size, num_heads, channels, num_levels, raw_query_stride);
+    if (op_ok && impl == 1)
+        return msda_backward_onepass_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                           reference_points, ref_batch_stride, stats, out, batch, spatial_size, num_heads,
+                                           channels, num_levels, grad_value, grad_raw);
+    int rc = op_ok && impl == 0
+                 ? msda_backward_scatter_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                               reference_points, ref_batch_stride, stats, batch, spatial_size, num_heads, channels,
+                                               num_levels, grad_value)
+                 : msda_backward_value_tile_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                                  reference_points, ref_batch_stride, stats, batch, spatial_size, num_heads,
+                                                  channels, num_levels, grad_value);
     if (rc) return rc;
     return msda_backward_fused_sampling(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
                                         reference_points, ref_batch_stride, stats, out, batch, spatial_size, num_heads,

@@ -18,13 +18,17 @@ template <typename T, int G> __device__ __forceinline__ T group_sum(T v)
 // a wave must call it (idx past the end is fine): all G lanes of a group stay converged (same (b,q,m) => same
 // branch decisions), which is what makes the shuffles legal.
 // VALUE_GRAD = false: grad_sampling_loc / grad_attn_weight only.
-template <typename T, int VEC, int G, bool VALUE_GRAD = true>
+// SAMPLING_GRAD = false: grad_value only (the one-pass kernel's grad_value-only variant, whose sampling gradients come from
+// another kernel).
+template <typename T, int VEC, int G, bool VALUE_GRAD = true, bool SAMPLING_GRAD = true>
 __device__ __forceinline__ void msda_bwd_lanes_body(
     int64_t idx, const T *__restrict__ grad_col, const T *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const T *__restrict__ loc, const T *__restrict__ aw, int B, int S,
     int M, int D, int L, int Lq, int P, T *__restrict__ grad_value, T *__restrict__ grad_loc,
-    T *__restrict__ grad_aw)
+    T *__restrict__ grad_aw, int l_begin = 0, int l_end = -1)
 {
+    // [l_begin, l_end): the levels this call covers (default: all; the one-pass kernel's stand-down jobs own one level)
+    if (l_end < 0) l_end = L;
     const int64_t total = (int64_t)B * Lq * M * G;
     const bool live = idx < total;
     const int64_t cidx = live ? idx : total - 1;
@@ -38,7 +42,7 @@ __device__ __forceinline__ void msda_bwd_lanes_body(
     const T *wp = aw + bqm * L * P;
     const int64_t voff = (int64_t)b * S * row + (int64_t)m * D + cg * VEC;
     const Pack<T, VEC> go = Pack<T, VEC>::load(grad_col + bqm * D + cg * VEC);
-    for (int l = 0; l < L; ++l) {
+    for (int l = l_begin; l < l_end; ++l) {
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
         const int64_t poff = voff + lsi[l] * row;
         for (int p = 0; p < P; ++p) {
@@ -77,7 +81,7 @@ __device__ __forceinline__ void msda_bwd_lanes_body(
             g_a = group_sum<T, G>(g_a);
             g_x = group_sum<T, G>(g_x);
             g_y = group_sum<T, G>(g_y);
-            if (live && cg == 0) {
+            if (SAMPLING_GRAD && live && cg == 0) {
                 grad_aw[bqm * L * P + t] = g_a;
                 grad_loc[(bqm * L * P + t) * 2 + 0] = T(W) * a * g_x;
                 grad_loc[(bqm * L * P + t) * 2 + 1] = T(H) * a * g_y;

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "msda_dispatch.h"
 #include "msda_tile.h"
+#include "msda_backward_lanes.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -87,148 +88,6 @@ __device__ __forceinline__ void corners_from_memory_half(const float *__restrict
     }
 }
 
-template <typename Cfg, int NL>
-__global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_sampling_tile(
-    const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
-    const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
-    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw, const int *__restrict__ local_hits)
-{
-    extern __shared__ __attribute__((aligned(16))) float vwin[];
-    constexpr int D = Cfg::D, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, SLICE = Cfg::SLICE, P = TILE_P;
-    constexpr int NV = Cfg::NV, NSTAGE = Cfg::NSTAGE, LCH = SLICE / 2, RPP = Cfg::ROWS_PER_PASS;
-    static_assert(NV == 4 && LCH == 16, "lanes own 16 channels");
-    static_assert(Cfg::THREADS == TH * TW * 2, "every lane owns a (cell, 16-channel half)");
-    const int tid = threadIdx.x;
-    const int HS = M * D / SLICE;
-    const int64_t row = (int64_t)M * D;
-
-    bool equal = true;
-    for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
-    if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
-
-    const int Hq = (int)shapes[0], Wq = (int)shapes[1];
-    const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
-    const int units = per_level * HS * B, units8 = (units + 7) / 8;
-    const float fW = (float)Wq, fH = (float)Hq;
-
-    const int sub = tid & 1, qi = tid >> 1, qly = qi / TW, qlx = qi % TW;
-    const int rot = (qlx / Cfg::TOK_PER_BANKROW) & (NV - 1);          // see msda_tile_body.h: LDS bank spreading
-    const int lane_off = sub * LCH;
-    // window copy: thread moves float4 `my_part` of window column `my_col`, rows my_row0 + i * RPP
-    const int my_part = tid % Cfg::PARTS, my_slot = tid / Cfg::PARTS;
-    const int my_row0 = my_slot / WW, my_col = my_slot % WW;
-    const bool col_ok = my_row0 < RPP;
-
-    // t enumerates xcd x (unit of that xcd) x query level: the L query levels (cameras) of one (tile, slice) run
-    // back to back on one XCD, so all but the first find the source windows in that L2 (as in msda_tile_body.h)
-    for (int t = blockIdx.x; t < units8 * 8 * L; t += gridDim.x) {
-        const int xcd = t & 7, r = t >> 3;
-        const int lq = r % L, unit = xcd * units8 + r / L;
-        if (r / L >= units8 || unit >= units) continue;
-        const int hs = unit % HS, u2 = unit / HS;
-        const int tin = u2 % per_level, b = u2 / per_level;
-        const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
-        const int ch0 = hs * SLICE + lane_off, head = ch0 / D;
-        const int qy = Y0 + qly, qx = X0 + qlx;
-        const bool active = qy < Hq && qx < Wq;
-        const int64_t q = (int64_t)b * S + lsi[lq] + (active ? (int64_t)qy * Wq + qx : 0);
-        const int64_t e0 = (q * M + head) * L * P;            // this (query, head)'s first tap
-        const float *vbatch = value + (int64_t)b * S * row + hs * SLICE;
-        const int oy = Y0 + TH / 2 - WH / 2, ox = X0 + TW / 2 - WW / 2;   // (a slice holds two heads here: no per-head shift)
-        const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
-
-        float4 g[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const float4 *>(go + q * row + ch0 + ((k ^ rot) << 2));
-        // the (query, head)'s gradients of all levels stay in registers and leave as one contiguous run at the end:
-        // written level by level they would be 16/32-byte pieces 112/224 bytes apart, i.e. partial-line writes
-        float4 r_aw[NL], r_l0[NL], r_l1[NL];
-
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            if (l >= L) continue;                             // (uniform; `break` would keep the loop from unrolling)
-            __syncthreads();                                  // everyone is done reading the old window
-            {
-                // window copy by LDS-DMA (buffer_load ... lds), as in msda_forward_group.hip: a wave's 64 lanes are the
-                // 8 x 16-byte chunks of 8 consecutive window positions = 1 KB contiguous in LDS behind a wave-uniform
-                // base; no staging registers (the register-staged copy held 80 of them), no ds_write; positions outside
-                // the level are out-of-range reads and store zeros
-                const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-                    const_cast<float *>(vbatch), 0, (int)((unsigned)S * (unsigned)row * 4u - (unsigned)(hs * SLICE) * 4u), 0x00020000);
-                const int gx = ox + my_col;
-                const bool xok = (unsigned)gx < (unsigned)Wq;
-                const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-                const unsigned so = (unsigned)((int)lsi[l] * (int)row) * 4u;
-                if (col_ok) {
-#pragma unroll
-                    for (int i = 0; i < NSTAGE; ++i) {
-                        const int wy = my_row0 + i * RPP, gy = oy + wy;
-                        if (wy < WH) {
-                            const unsigned vo = (xok && (unsigned)gy < (unsigned)Hq) ? (unsigned)((gy * Wq + gx) * (int)row + my_part * 4) * 4u : 0x80000000u;
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(vwin + (i * RPP * WW + wave_u * 8) * SLICE),
-                                                                     16, (int)vo, (int)so, 0, 0);
-                        }
-                    }
-                }
-            }
-            const float4 la = *reinterpret_cast<const float4 *>(loc + (e0 + l * P) * 2);
-            const float4 lb = *reinterpret_cast<const float4 *>(loc + (e0 + l * P) * 2 + 4);
-            const float4 wa = *reinterpret_cast<const float4 *>(aw + e0 + l * P);
-            __syncthreads();
-
-            const float xs[4] = {la.x * fW - 0.5f, la.z * fW - 0.5f, lb.x * fW - 0.5f, lb.z * fW - 0.5f};
-            const float ys[4] = {la.y * fH - 0.5f, la.w * fH - 0.5f, lb.y * fH - 0.5f, lb.w * fH - 0.5f};
-            const float as[4] = {wa.x, wa.y, wa.z, wa.w};
-            float ga[4], gx[4], gy[4];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const float x = xs[p], y = ys[p];
-                f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
-                if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
-                    const int ix = (int)floorf(x) - ox, iy = (int)floorf(y) - oy;
-                    const float *p00 = vwin + __mul24(iy * WW + ix, SLICE) + lane_off;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        const float *pk = p00 + ((k ^ rot) << 2);
-                        q00 = dot4(g[k], *reinterpret_cast<const float4 *>(pk), q00);
-                        q01 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + SLICE), q01);
-                        q10 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * SLICE), q10);
-                        q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * SLICE + SLICE), q11);
-                    }
-                } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {       // (lanes without a cell carry cell 0's taps)
-                    corners_from_memory<NV>(vbatch + lsi[l] * row + lane_off, row, Hq, Wq, x, y, rot, g, q00, q01, q10, q11);
-                }
-                float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
-                if constexpr (D > LCH) {                      // the other half of the head sits in the neighbouring lane
-                    d00 += __shfl_xor(d00, 1, 64);
-                    d01 += __shfl_xor(d01, 1, 64);
-                    d10 += __shfl_xor(d10, 1, 64);
-                    d11 += __shfl_xor(d11, 1, 64);
-                }
-                const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
-                ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
-                gx[p] = in_image ? fW * as[p] * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-                gy[p] = in_image ? fH * as[p] * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
-                __builtin_amdgcn_sched_barrier(0);            // one tap's 16 LDS reads in flight at a time
-            }
-            r_aw[l] = make_float4(ga[0], ga[1], ga[2], ga[3]);
-            r_l0[l] = make_float4(gx[0], gy[0], gx[1], gy[1]);
-            r_l1[l] = make_float4(gx[2], gy[2], gx[3], gy[3]);
-        }
-        if (active && (D == LCH || sub == 0)) {
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                if (l >= L) continue;
-                *reinterpret_cast<float4 *>(grad_aw + e0 + l * P) = r_aw[l];
-                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2) = r_l0[l];
-                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2 + 4) = r_l1[l];
-            }
-        }
-    }
-}
-
 // ---- all source windows resident: D = 16, L <= 7 (MVDeTr's own shapes) ------------------------------------------------
 // msda_bwd_sampling_tile stages the L source windows once per QUERY level: 7 x 7 windows of 72 KB per 128 cells,
 // 1.35 GB of L2->LDS copies per launch at Wildtrack size, most of them L2 misses (FETCH_SIZE 1.18 GB) -- and between two
@@ -284,8 +143,33 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
         const int64_t q = (int64_t)b * S + lsi[cam] + (active ? (int64_t)qy * Wq + qx : 0);
         const int64_t e0 = (q * M + head) * L * P;            // this (query, head)'s first tap
         const float *vbatch = value + (int64_t)b * S * row + head * D;
-        int shx, shy;                                         // where this head's taps lie (locality probe, msda_dispatch.h)
-        msda_probe_shift(local_hits, head, shx, shy);
+        int shx, shy;                                         // where this head's taps lie
+        if (local_hits) {
+            msda_probe_shift(local_hits, head, shx, shy);     // (the probe launch of rounds 2-4's callers)
+        } else {
+            // no probe: the job's own sample -- camera 0's taps of the tile's 32 cells at level 0 (both half lanes of a cell
+            // carry the same values) -- gives the shift and says whether the windows are worth staging at all
+            const int s_qi = lane >> 1, s_qy = Y0 + s_qi / TW, s_qx = X0 + s_qi % TW;
+            const bool have = s_qy < Hq && s_qx < Wq;
+            const float *lp = loc + ((((int64_t)b * S + lsi[0] + (have ? (int64_t)s_qy * Wq + s_qx : 0)) * M + head) * L) * P * 2;
+            const float4 a0 = *reinterpret_cast<const float4 *>(lp), b0 = *reinterpret_cast<const float4 *>(lp + 4);
+            bool far;
+            msda_job_sample(a0, b0, have, s_qx, s_qy, fW, fH, shx, shy, far);
+            if (far) {
+                // far-flung taps: this job's (cell, camera) items through the lane-group body, sampling gradients only
+                const int items = TH * TW * L * D;
+                for (int it = tid; it < (items + RS_THREADS - 1) / RS_THREADS * RS_THREADS; it += RS_THREADS) {
+                    const int cg = it % D, ci = (it / D) % (TH * TW), c = it / (D * TH * TW);
+                    const int y_ = Y0 + ci / TW, x_ = X0 + ci % TW;
+                    const bool ok = it < items && y_ < Hq && x_ < Wq;
+                    const int64_t qq = ok ? (int64_t)b * S + lsi[c] + (int64_t)y_ * Wq + x_ : -1;
+                    const int64_t idx = ok ? (qq * M + head) * D + cg : (int64_t)B * S * M * D + cg;
+                    msda_bwd_lanes_body<float, 1, D, false>(idx, go, value, shapes, lsi, loc, aw, B, S, M, D, L, S, P, nullptr,
+                                                            grad_loc, grad_aw);
+                }
+                continue;
+            }
+        }
         const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
 
@@ -428,8 +312,31 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
         const int qy = Y0 + qly, qx = X0 + qlx;
         const bool in_level = qy < Hq && qx < Wq;
         const float *vbatch = value + (int64_t)b * S * row + head * D;
-        int shx, shy;                                         // where this head's taps lie (locality probe, msda_dispatch.h)
-        msda_probe_shift(local_hits, head, shx, shy);
+        int shx, shy;                                         // where this head's taps lie
+        if (local_hits) {
+            msda_probe_shift(local_hits, head, shx, shy);     // (the probe launch of rounds 2-4's callers)
+        } else {
+            // no probe: the job's own sample (see msda_bwd_sampling_resident)
+            const int s_qi = lane >> 1, s_qy = Y0 + s_qi / TW, s_qx = X0 + s_qi % TW;
+            const bool have = s_qy < Hq && s_qx < Wq;
+            const float *lp = loc + ((((int64_t)b * S + lsi[0] + (have ? (int64_t)s_qy * Wq + s_qx : 0)) * M + head) * L) * P * 2;
+            const float4 a0 = *reinterpret_cast<const float4 *>(lp), b0 = *reinterpret_cast<const float4 *>(lp + 4);
+            bool far;
+            msda_job_sample(a0, b0, have, s_qx, s_qy, fW, fH, shx, shy, far);
+            if (far) {
+                const int items = TH * TW * L * D;
+                for (int it = tid; it < (items + RS_THREADS - 1) / RS_THREADS * RS_THREADS; it += RS_THREADS) {
+                    const int cg = it % D, ci = (it / D) % (TH * TW), c = it / (D * TH * TW);
+                    const int y_ = Y0 + ci / TW, x_ = X0 + ci % TW;
+                    const bool ok = it < items && y_ < Hq && x_ < Wq;
+                    const int64_t qq = ok ? (int64_t)b * S + lsi[c] + (int64_t)y_ * Wq + x_ : -1;
+                    const int64_t idx = ok ? (qq * M + head) * D + cg : (int64_t)B * S * M * D + cg;
+                    msda_bwd_lanes_body<float, 1, D, false>(idx, go, value, shapes, lsi, loc, aw, B, S, M, D, L, S, P, nullptr,
+                                                            grad_loc, grad_aw);
+                }
+                continue;
+            }
+        }
         const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
 
@@ -563,44 +470,15 @@ static int launch_sampling_resident(hipStream_t st, const float *go, const float
     return (int)hipGetLastError();
 }
 
-using SWide16 = TileCfg<16, 32, 8, 16, 6>;
-using SWide32 = TileCfg<32, 32, 8, 16, 6>;
-
-template <typename Cfg, int NL>
-static int launch_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
-                                const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
-                                float *grad_loc, float *grad_aw, const int *local_hits)
-{
-    static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_tile<Cfg, NL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        int dev = 0, cus = 256, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_sampling_tile<Cfg, NL>, Cfg::THREADS,
-                                                         Cfg::LDS_BYTES) != hipSuccess || per_cu < 1)
-            per_cu = 2;
-        return (cus * per_cu + 7) / 8 * 8;
-    }();
-    hipLaunchKernelGGL((msda_bwd_sampling_tile<Cfg, NL>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES, st,
-                       go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits);
-    return (int)hipGetLastError();
-}
-
 int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                 const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                                 float *grad_loc, float *grad_aw, const int *local_hits)
 {
 #define SAMPLING_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits
-    static const bool resident_ok = [] { const char *e = getenv("MVDETR_MSDA_BWD_SAMPLING"); return !(e && !strcmp(e, "tile")); }();
-    if (resident_ok && D == RS_D && L <= RS_MAXL && (int64_t)S * M * D * 4 < 0x7fffffffLL) return launch_sampling_resident(SAMPLING_ARGS);
+    if (D == RS_D && L <= RS_MAXL && (int64_t)S * M * D * 4 < 0x7fffffffLL) return launch_sampling_resident(SAMPLING_ARGS);
     // more levels or 32-channel heads: the same job with the levels passing through LDS in groups
-    // (MVDETR_MSDA_BWD_SAMPLING=tile keeps the per-query-level tile kernel)
-    if (resident_ok && D == 32) return launch_sampling_groups<32, 3>(SAMPLING_ARGS);
-    if (resident_ok && D == 16) return launch_sampling_groups<16, 7>(SAMPLING_ARGS);
-    if (D == 16) return L <= 8 ? launch_sampling_tile<SWide16, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide16, 16>(SAMPLING_ARGS);
-    if (D == 32) return L <= 8 ? launch_sampling_tile<SWide32, 8>(SAMPLING_ARGS) : launch_sampling_tile<SWide32, 16>(SAMPLING_ARGS);
+    if (D == 32) return launch_sampling_groups<32, 3>(SAMPLING_ARGS);
+    if (D == 16) return launch_sampling_groups<16, 7>(SAMPLING_ARGS);
     return (int)hipErrorInvalidValue;
 }
 

@@ -68,6 +68,23 @@ int msda_backward_value_tile_fused(hipStream_t st, const float *go, const float 
 int msda_backward_fused_sampling(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                  const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                  const float *stats, const float *out_fwd, int B, int S, int M, int D, int L, float *grad_raw);
+// the whole encoder-shaped fp32 backward in ONE kernel (msda_backward_onepass.hip): 16-channel heads; no probe, no scratch
+bool msda_backward_onepass_supported(int B, int S, int M, int D, int L, int64_t q_floats);
+int msda_backward_onepass(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *loc, const float *aw, int B, int S, int M, int D, int L, float *grad_value,
+                          float *grad_loc, float *grad_aw, bool standdown);
+int msda_backward_onepass_fused(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                const float *stats, const float *out_fwd, int B, int S, int M, int D, int L,
+                                float *grad_value, float *grad_raw);
+// the grad_value half of the same kernel alone (no value window, no dot products): what the two-kernel backward launches for
+// grad_value since round 5 (units of L level jobs, guessed fixed-point scale, in-kernel window shift and stand-down)
+int msda_backward_scatter(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *loc, const float *aw, int B, int S, int M, int D, int L, float *grad_value,
+                          float *grad_loc, float *grad_aw, bool standdown);
+int msda_backward_scatter_fused(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                const float *stats, int B, int S, int M, int D, int L, float *grad_value);
 // device-side locality probe shared by the kernels of a call (stream-ordered scratch of MSDA_PROBE_INTS ints):
 //   probe[0]              how many of MSDA_PROBE_SAMPLES sampled taps lie within MSDA_PROBE_RADIUS pixels of their own query cell
 //   probe[1 + 3 m + 0..2] for head m (< MSDA_PROBE_MAXHEADS): sum of the sampled taps' x / y displacement from their own cell in
@@ -93,6 +110,45 @@ __device__ __forceinline__ void msda_probe_shift(const int *__restrict__ probe, 
     const float inv = 1.f / (16.f * (float)n);
     sx = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf((float)probe[1 + 3 * head] * inv)));
     sy = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf((float)probe[1 + 3 * head + 1] * inv)));
+}
+// The same two answers WITHOUT a probe launch (round 5): every wave of a workgroup reduces ONE sample of the job -- 64 lanes'
+// worth of (cell, 4 points) locations of camera 0, the job's head and one level, the same sample in every wave -- to the mean
+// tap displacement (the window shift) and to whether fewer than 1 / MSDA_PROBE_NEAR_DIV of the sampled taps lie within
+// MSDA_PROBE_RADIUS pixels of their own cell (`far`: the job computes its taps in the lane-group formulation instead of
+// staging windows).  All waves see the same data and do the same arithmetic: the results are workgroup-uniform without LDS
+// or a barrier.  la / lb: the lane's four normalised (x, y) locations; have: the lane holds a cell of the map.
+__device__ __forceinline__ void msda_job_sample(const float4 &la, const float4 &lb, bool have, int qx, int qy, float fW, float fH,
+                                                int &shx, int &shy, bool &far)
+{
+    float sx = 0.f, sy = 0.f, sn = 0.f, snear = 0.f, scnt = 0.f;
+    if (have) {
+        const float mx = 0.25f * ((la.x + la.z) + (lb.x + lb.z)) * fW - 0.5f - (float)qx;
+        const float my = 0.25f * ((la.y + la.w) + (lb.y + lb.w)) * fH - 0.5f - (float)qy;
+        if (mx == mx && my == my && fabsf(mx) < 64.f && fabsf(my) < 64.f) { sx = mx; sy = my; sn = 1.f; }
+        const float ox_ = (float)qx + 0.5f, oy_ = (float)qy + 0.5f, rr = MSDA_PROBE_RADIUS;
+        snear = (float)((fabsf(la.x * fW - ox_) < rr && fabsf(la.y * fH - oy_) < rr) + (fabsf(la.z * fW - ox_) < rr && fabsf(la.w * fH - oy_) < rr) +
+                        (fabsf(lb.x * fW - ox_) < rr && fabsf(lb.y * fH - oy_) < rr) + (fabsf(lb.z * fW - ox_) < rr && fabsf(lb.w * fH - oy_) < rr));
+        scnt = 4.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, 64);
+        sy += __shfl_xor(sy, o, 64);
+        sn += __shfl_xor(sn, o, 64);
+        snear += __shfl_xor(snear, o, 64);
+        scnt += __shfl_xor(scnt, o, 64);
+    }
+    const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
+    const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy)));
+    const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
+    const float tl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, snear)));
+    const float tc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scnt)));
+    shx = shy = 0;
+    if (tn > 0.f) {
+        shx = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf(tx / tn)));
+        shy = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf(ty / tn)));
+    }
+    far = tl * (float)MSDA_PROBE_NEAR_DIV < tc;
 }
 int msda_launch_locality_probe(hipStream_t st, const float *loc, const int64_t *shapes, int B, int S, int M, int L, int *hits);
 

@@ -236,6 +236,10 @@ class MSDeformAttn(nn.Module):
                 and reference_points.dim() == 5 and reference_points.shape[-1] == 2
                 and query.is_cuda and query.dtype == torch.float32 and value.is_cuda and value.dtype == torch.float32
                 and reference_points.is_cuda and reference_points.dtype == torch.float32
+                # (the fused function returns no gradient for the reference points: learned / refined points keep the
+                # differentiable path below)
+                and not reference_points.requires_grad
+                and (shared_reference is None or not shared_reference.requires_grad)
                 and MSDA.fused_train_supported(N, Len_in, M, D, self.n_levels, Len_q, self.n_points)
                 and self._levels_equal(input_spatial_shapes)):
             shared = shared_reference if shared_reference is not None else self._shared_reference(reference_points)
@@ -246,9 +250,13 @@ class MSDeformAttn(nn.Module):
                 w, b = self._fused_projection_train()
                 raw = F.linear(query, w, b)
                 value4 = value.view(N, Len_in, M, D).contiguous()
-                if value4.data_ptr() % 16 == 0 and raw.data_ptr() % 16 == 0:
+                shared = shared.contiguous()
+                # the kernels' contract: fp32 everywhere (autocast may have made `raw` 16-bit), 16-byte aligned tensors,
+                # 8-byte aligned reference points; anything else takes the unfused path below instead of raising
+                if (raw.dtype == torch.float32 and shared.dtype == torch.float32 and value4.data_ptr() % 16 == 0
+                        and raw.data_ptr() % 16 == 0 and shared.data_ptr() % 8 == 0):
                     out = MSDeformAttnFusedFunction.apply(value4, input_spatial_shapes, input_level_start_index,
-                                                          shared.contiguous(), raw)
+                                                          shared, raw)
                     return self.output_proj(out)
         value = value.view(N, Len_in, M, D)
         offsets = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)

@@ -6,6 +6,9 @@ also frameDataset.py:80, grid_visualize.py:19-21).  Differentiable w.r.t. ``src`
 """
 from __future__ import annotations
 
+import os
+import threading
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -79,33 +82,49 @@ class _BackwardPlans:
     texels) for the matrices seen lately.  A plan depends on M and the shapes only, so training without augmentation -- the
     same projection matrices every iteration -- builds it once and every backward is ONE kernel.  Entries hold the matrix
     tensor itself (its storage cannot be handed to another tensor while cached) and its version counter; writes through
-    ``.data`` are invisible to it, like to autograd."""
+    ``.data`` are invisible to it, like to autograd.
+
+    Autograd runs backwards on one thread per device, so the cache is guarded by a lock and partitioned per (device, stream):
+    a plan is only ever reused on the stream that built it (no cross-stream ordering to get wrong), every partition keeps its
+    own ``KEEP`` most recent plans (a DataParallel run's replicas do not evict each other), and the library's geometry knobs
+    (``MVDETR_WARP_BWD_GEOMETRY`` / ``MVDETR_WARP_BWD_HEAVY``, which change a plan's contents) are part of the key."""
     KEEP = 4
 
     def __init__(self):
-        self.entries = []          # (M, version, shapes, plan), most recent first
+        self.lock = threading.Lock()
+        self.parts = {}            # (device index, stream pointer) -> [(M, version, key, plan), ...], most recent first
 
     def get(self, M, shapes):
         n, c, h, w, H, W = shapes
-        for i, (m, ver, shp, plan) in enumerate(self.entries):
-            if shp == shapes and m.data_ptr() == M.data_ptr() and ver == M._version and m.device == M.device and m.dtype == M.dtype:
-                if i:
-                    self.entries.insert(0, self.entries.pop(i))
-                return plan
+        stream = _lib.current_stream_ptr(M.device)
+        part_key = (M.device.index, int(stream or 0))
+        key = (shapes, os.environ.get("MVDETR_WARP_BWD_GEOMETRY"), os.environ.get("MVDETR_WARP_BWD_HEAVY"))
+        with self.lock:
+            entries = self.parts.setdefault(part_key, [])
+            for i, (m, ver, k, plan) in enumerate(entries):
+                if k == key and m.data_ptr() == M.data_ptr() and ver == M._version and m.dtype == M.dtype:
+                    if i:
+                        entries.insert(0, entries.pop(i))
+                    return plan
         nbytes = int(_lib.lib().mvdetr_warp_backward_plan_bytes(n, c, h, w, H, W, M.element_size()))
         if nbytes <= 0:
             return None
         plan = torch.empty(nbytes, dtype=torch.uint8, device=M.device)
         with torch.cuda.device(M.device):
             rc = getattr(_lib.lib(), f"mvdetr_warp_backward_plan_{_lib.suffix(M.dtype)}")(
-                _lib.current_stream_ptr(M.device), M.data_ptr(), n, c, h, w, H, W, plan.data_ptr())
+                stream, M.data_ptr(), n, c, h, w, H, W, plan.data_ptr())
         if rc == 801:                                        # hipErrorNotSupported: the scatter kernels take the call
             return None
         _lib.check(rc, "warp_backward_plan")
-        # (a plan built on one stream and used on another: the caching allocator's stream semantics apply, as for any tensor)
-        self.entries.insert(0, (M, M._version, shapes, plan))
-        del self.entries[self.KEEP:]
+        with self.lock:
+            entries = self.parts.setdefault(part_key, [])
+            entries.insert(0, (M, M._version, key, plan))
+            del entries[self.KEEP:]
         return plan
+
+    def clear(self):
+        with self.lock:
+            self.parts.clear()
 
 
 _plans = _BackwardPlans()
