@@ -253,6 +253,13 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
             "frac": round(wbytes / (us_p * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
             "what": "mvdetr_warp_perspective_backward_planned_f32 with the plan of mvdetr_warp_backward_plan_f32 reused (what "
                     "WarpPerspectiveFunction.backward does while the matrices do not change)"}
+        # ... and what a C-ABI caller gets with the one-call entry and a version tag of its matrices (ABI 12): the library keeps
+        # the plan in its own per-(device, stream) scratch while the tag stays
+        us_t, mn_t = time_launches(lambda: warp_mod._launch("backward", go, pm, N, C, h, w, H, W, 3, gs, tag=0x5eed), launches)
+        out["roofline_warp_bwd"]["tagged"] = {
+            "kernel": warp_mod.last_kernel(), "avg_launch_us": round(us_t, 2), "min_launch_us": round(mn_t, 2),
+            "frac": round(wbytes / (us_t * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+            "what": "mvdetr_warp_perspective_backward_tagged_f32, same tag on every call: one launch (the gather) per call"}
         del go, gs
         # MSDA backward at this configuration's encoder shape, SURVEY 8d's input (bias grid + N(0, 1 px) offsets)
         wf = model.world_feat
@@ -264,7 +271,8 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
         bbytes = 4 * (S * M_ * D_ + 2 * S * M_ * D_ + 6 * S * M_ * N * 4)   # 4 (Lq M D + 2 S M D + 6 Lq M L P)
         us, mn = time_launches(lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, gout, 64), launches)
         out["roofline_msda_bwd"] = roofline_entry(
-            "msda_bwd_value_tok + msda_bwd_sampling_resident (+ locality probe, memset of grad_value)" if (D_ == 16 and N <= 7)
+            "msda_bwd_onepass<grad_value only> + msda_bwd_sampling_resident (+ memset of grad_value; no probe launch)" if (D_ == 16 and N <= 7)
+            else "msda_bwd_onepass<grad_value only> + msda_bwd_sampling_groups (+ memset of grad_value)" if D_ == 16
             else "msda_bwd_value_tok + msda_bwd_sampling_groups (+ locality probe, memset of grad_value)", us, mn, bbytes, launches,
             "MultiScaleDeformableAttention.ms_deform_attn_backward (public contract), SURVEY 8d's locality-realistic input: "
             "bias grid + N(0, 1 px) offsets, softmax(N(0,1)) weights")
@@ -286,11 +294,19 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
             out["roofline_iid_offsets"] = roofline_entry(
                 MSDA.last_forward_kernel(), us_i, mn_i, fbytes, launches,
                 "mvdetr_msda_forward_fused_f32 on SURVEY 8d's microbenchmark input: bias grid + iid N(0, 1 px) per tap, logits N(0, 1)")
+            sweep = {}
+            for px in (0.5, 2.0, 4.0):
+                raw_s = fused_train_inputs(N, hh, ww, M_, D_, 4, seed=0, noise_px=px)[4].to(feat.device)
+                us_s, _ = time_launches(lambda: MSDA.ms_deform_attn_forward_fused(value, shapes, lsi, ref_lm, None, None, raw=raw_s,
+                                                                                   ref_level_major=True, raw_level_outer=True), 6)
+                sweep[f"{px:g}px"] = {"avg_launch_us": round(us_s, 2), "frac": round(fbytes / (us_s * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
+                del raw_s
+            out["roofline_iid_offsets"]["spread_sweep"] = sweep
             o_, st_ = MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw)
             us_f, mn_f = time_launches(lambda: MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw), launches)
             us_b, mn_b = time_launches(lambda: MSDA.ms_deform_attn_backward_fused(gout, value, shapes, lsi, ref_lm, raw, st_, o_), launches)
             out["roofline_train_step"] = roofline_entry(
-                "msda_fwd_group2 (+ statistics) ; msda_bwd_value_tok<fused> + msda_bwd_fused_sampling (+ memset of grad_value)",
+                "msda_fwd_group2 (+ statistics) ; msda_bwd_onepass<fused, grad_value only> + msda_bwd_fused_sampling (+ memset of grad_value)",
                 us_f + us_b, mn_f + mn_b, fbytes + bbytes, launches,
                 "mvdetr_msda_forward_fused_train_f32 + mvdetr_msda_backward_fused_f32 on the same realistic input in raw form",
                 {"forward_us": round(us_f, 2), "backward_us": round(us_b, 2),
@@ -489,23 +505,29 @@ def main():
         offset_calibration = calibrate_sampling(attn_layers, cal_run, offset_std)
 
     tuning_shared = None
-    rank0_first = world > 1 and gemm_tuning and a.parallel == "dp"
+    rank0_first = world > 1 and gemm_tuning
     if not rank0_first:
         calibrate()
         clock.mark("offset_calibration_incl_miopen_find")     # (the first frames of the process run here)
     else:
-        # (dp only: a view-sharded step has collectives in it, rank 0 cannot run it alone)
-        # rank 0 goes first -- calibration frames and warm-up steps: TunableOp's measured GEMM picks go to ONE results file and
-        # MIOpen's find results to its user database; the other ranks then read both instead of each spending minutes
-        # measuring the same shapes at the same time.  Every rank runs the same barrier sequence whatever fails in between.
+        # rank 0 goes first -- calibration frames and (dp) warm-up steps: TunableOp's measured GEMM picks go to ONE results file
+        # and MIOpen's find results to its user database; the other ranks then read both instead of each spending minutes
+        # measuring the same shapes at the same time.  `--parallel views`: a view-sharded step has collectives in it, so rank 0
+        # cannot run IT alone -- but the calibration frame is the unsharded model and has none: rank 0 runs that one frame first
+        # (the trunk's and the replicated encoder's shapes are then known; what only a shard sees is found by every rank in the
+        # warm-up steps as before).  Every rank runs the same barrier sequence whatever fails in between.
         tun = torch.cuda.tunable
         shared = os.path.join(tempfile.gettempdir(), f"mvdetr_bench_tunableop_shared_{os.environ.get('MASTER_PORT', '0')}.csv")
         tuning_shared = True
         if rank == 0:
             try:
                 calibrate()
-                for _ in range(max(a.warmup, 1)):
-                    step()
+                if a.parallel == "dp":
+                    for _ in range(max(a.warmup, 1)):
+                        step()
+                elif offset_calibration is None:           # (nothing to calibrate: still one unsharded frame for the libraries)
+                    with torch.no_grad():
+                        model(torch.randn(1, N, 3, Hi, Wi, generator=torch.Generator().manual_seed(1000)).to(dev), M[:1])
                 torch.cuda.synchronize()
                 write_tunableop_results(tun, shared)
             except Exception as ex:                # pragma: no cover
@@ -627,6 +649,31 @@ def main():
                 at.attention_weights.weight.copy_(aw)
                 at.cache_fused_projection(True)
 
+    # ---- how the same kernel degrades with the spread of the learned offsets: the calibrated (1 px) offset projections scaled
+    #      to 0.5 / 1 / 2 / 4 px, in the model (exact for the first layer; later layers' queries move a little with it) ----------
+    spread_sweep = None
+    if a.parallel == "dp" and offset_calibration and attn_layers and not a.no_kernel_rooflines:
+        saved = [at.sampling_offsets.weight.detach().clone() for at in attn_layers]
+        spread_sweep = {}
+        with torch.no_grad():
+            for px in (0.5, 1.0, 2.0, 4.0):
+                for at, ow in zip(attn_layers, saved):
+                    at.sampling_offsets.weight.copy_(ow * (px / offset_std))
+                    at.cache_fused_projection(True)
+                model.hot_path(feat, proj)
+                n0 = len(timer.events)
+                timer.enabled = True
+                for _ in range(4):
+                    model.hot_path(feat, proj)
+                torch.cuda.synchronize()
+                timer.enabled = False
+                ts = [e0.elapsed_time(e1) * 1e3 for e0, e1, _ in timer.events[n0:]]
+                del timer.events[n0:]
+                spread_sweep[f"{px:g}px"] = round(sum(ts) / len(ts), 2)
+            for at, ow in zip(attn_layers, saved):
+                at.sampling_offsets.weight.copy_(ow)
+                at.cache_fused_projection(True)
+
     clock.mark("hot_path_and_init_weight_runs")
     if rank != 0:
         return
@@ -660,6 +707,12 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                      "avg_launch_us": round(k_us, 2) if k_us else None, "launches_timed": k_n,
                      "code_object": fwd_resources,
+                     "spread_sweep": ({"what": "avg launch us of the same kernel in the model with the calibrated offset projections scaled "
+                                               "to the given spread (frac = algorithmic bytes / us / 8 TB/s); `roofline` itself is quoted "
+                                               "at 1 px and stays so",
+                                       "avg_launch_us": spread_sweep,
+                                       "frac": {k: round(alg_bytes / (v * 1e-6) / 1e9 / PEAK_HBM_GBS, 4) for k, v in spread_sweep.items()}}
+                                      if spread_sweep and alg_bytes else None),
                      "input": (f"learned-like offsets: bias grid + the model's own offset projection of its queries, calibrated per layer to "
                                f"a spread of {offset_std:g} px (SURVEY 8d: bias grid + N(0, 1 px); config.offset_calibration has the spreads before)" if offset_std
                                else "reference init: constant bias-grid offsets"),

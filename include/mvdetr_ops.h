@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 11   /* 11: + mvdetr_warp_release_scratch */
+#define MVDETR_OPS_ABI_VERSION 12   /* 12: + mvdetr_warp_perspective_backward_tagged_* */
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -207,6 +207,20 @@ int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, co
 int mvdetr_warp_perspective_backward_f64(void *stream, const double *grad_dst, const double *M,
                                          int n, int channels, int src_h, int src_w, int dst_h,
                                          int dst_w, int layout_nhwc, double *grad_src);
+
+/* The one-call gradient with a caller-supplied VERSION TAG of the matrices (ABI 12): `matrices_tag` != 0 is the caller's
+ * promise that calls with the same tag -- on this device and stream, with the same shapes -- pass the same M.  The library
+ * keeps the gather's geometry (see below) in its per-(device, stream) scratch together with the tag, so the second and later
+ * calls of a training loop without augmentation launch the gather alone: what mvdetr_warp_perspective_backward_* would do if
+ * it could compare M on the host (it cannot: M is a device pointer, and comparing it on the device would cost every call a
+ * dependent launch).  Tag 0 = unknown: identical to mvdetr_warp_perspective_backward_*.  A new tag (or an untagged call on
+ * the stream in between) rebuilds the geometry.  Replaces kornia.warp_perspective's backward at mvdetr.py:194-195. */
+int mvdetr_warp_perspective_backward_tagged_f32(void *stream, const float *grad_dst, const float *M, int n, int channels,
+                                                int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                uint64_t matrices_tag, float *grad_src);
+int mvdetr_warp_perspective_backward_tagged_f64(void *stream, const double *grad_dst, const double *M, int n, int channels,
+                                                int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                uint64_t matrices_tag, double *grad_src);
 
 /* The same gradient in two steps, for callers whose matrices stay the same from call to call (training without
  * augmentation: the projection matrices are constants, mvdetr.py:82-95,155-161).  The gather's geometry -- which destination

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # MVDETR_OPS_LIB: another build of the same sources (the phase-stamp build libmvdetr_ops_trace.so of tools/experiments)
 LIB_PATH = os.environ.get("MVDETR_OPS_LIB") or os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
@@ -56,6 +56,8 @@ SIGNATURES = {
     "mvdetr_warp_perspective_forward_f64": (_WARP, _i),
     "mvdetr_warp_perspective_backward_f32": (_WARP, _i),
     "mvdetr_warp_perspective_backward_f64": (_WARP, _i),
+    "mvdetr_warp_perspective_backward_tagged_f32": ([_vp] * 3 + [_i] * 7 + [ctypes.c_uint64, _vp], _i),
+    "mvdetr_warp_perspective_backward_tagged_f64": ([_vp] * 3 + [_i] * 7 + [ctypes.c_uint64, _vp], _i),
     "mvdetr_warp_backward_plan_bytes": ([_i] * 7, ctypes.c_int64),
     "mvdetr_warp_backward_plan_f32": ([_vp, _vp] + [_i] * 6 + [_vp], _i),
     "mvdetr_warp_backward_plan_f64": ([_vp, _vp] + [_i] * 6 + [_vp], _i),

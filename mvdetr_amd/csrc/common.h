@@ -88,6 +88,14 @@ __device__ __forceinline__ float4 load4_or_zero(const float *p, bool ok, const f
     return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access of the
+// wave (s_waitcnt vmcnt(0)): prefetched sampling data, fire-and-forget stores and atomics, a window copy that nothing behind
+// the barrier depends on yet.  Use it where only LDS reads / writes of other waves must have completed.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

@@ -139,7 +139,7 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
             if (!rc) rc = msda_backward_sampling_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_loc, grad_aw, nullptr);
             return rc;
         }
-        if (tile_shapes) {
+        if (tile_shapes && msda_backward_value_tile_fits(S, M, D, L)) {
             // rounds 2-4's pair (and 32-channel heads): a stream-ordered scratch int carries the locality probe's verdict to both
             // kernels: calls whose taps are far from their queries (e.g. uniformly random locations) run the lane-group
             // backward inside the first launch instead -- no host synchronisation
@@ -155,10 +155,8 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
     // One channel per lane (G = D lanes per head): a wave's atomic instruction then covers whole
     // 4*D-byte head segments, which the memory-side atomic units take as ONE request each, instead of four
     // partial ones with 16-byte-per-lane vectors (measured at Wildtrack size: 3.15 ms vs 12.7 ms -- the
-    // kernel is bound by atomic requests, ~21 G/s, not by bytes).  MVDETR_MSDA_BWD_VEC=wide restores the
-    // vector mapping for comparison.
-    static const bool scalar_lanes = [] { const char *e = getenv("MVDETR_MSDA_BWD_VEC"); return !(e && !strcmp(e, "wide")); }();
-    if (scalar_lanes && D <= 64 && (D & (D - 1)) == 0) {
+    // kernel is bound by atomic requests, ~21 G/s, not by bytes).
+    if (D <= 64 && (D & (D - 1)) == 0) {
         switch (D) {
         case 1: return launch_lanes<T, 1, 1>(st, MSDA_BWD_ARGS);
         case 2: return launch_lanes<T, 1, 2>(st, MSDA_BWD_ARGS);

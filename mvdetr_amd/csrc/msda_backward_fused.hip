@@ -231,7 +231,7 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
         for (int k = 0; k < NV; ++k) choff[k] = (k ^ rot) << 2;
 
         for (int l = 0; l < L; ++l) {
-            __syncthreads();
+            lds_barrier();                                    // (LDS only: see msda_fwd_group2)
             {
                 int t2 = tid;
                 asm volatile("" : "+v"(t2));
@@ -431,8 +431,7 @@ int msda_backward_fused_sampling(hipStream_t st, const float *go, const float *v
                                  const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                  const float *stats, const float *out_fwd, int B, int S, int M, int D, int L, float *grad_raw)
 {
-    static const bool blocks = [] { const char *e = getenv("MVDETR_MSDA_JOBMAP"); return !(e && !strcmp(e, "band")); }();
-    const int opts = blocks ? GROUP_OPT_BLOCKS : 0;
+    const int opts = GROUP_OPT_BLOCKS;
     if (D == 16 && L == 7)
         return launch_bwd_fused_sampling<GWide16, 7>(st, go, value, shapes, lsi, raw, raw_q, ref, ref_bstride, stats, out_fwd, B, S, M, grad_raw, opts);
     if (D == 16 && L == 6)

@@ -60,14 +60,6 @@ namespace {
 // pixel coordinate of a normalised location; ONE expression for every pass (a tap must be inside the window in all or in none)
 __device__ __forceinline__ float op_pix(float loc, float size) { return __fmaf_rn(loc, size, -0.5f); }
 
-// A workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the
-// wave (vmcnt(0)) -- here the flush's fire-and-forget atomics, the gradient stores of the last step and the next level's
-// window copy, none of which anything behind the barrier depends on.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -260,42 +252,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
             int lane_s = lane;
             asm volatile("" : "+v"(lane_s));   // (opaque: what derives from it is computed here, not kept alive from kernel entry)
             const int s_qy = Y0 + lane_s / TW, s_qx = X0 + lane_s % TW;
-            float sx = 0.f, sy = 0.f, sn = 0.f, snear = 0.f, scnt = 0.f;
-            if (s_qy < Hq && s_qx < Wq) {
-                float4 a0, b0, w0;
-                fetch((int64_t)b * S + lsi[0] + (int64_t)s_qy * Wq + s_qx, b, head, l_first, a0, b0, w0);
-                const float mx = 0.25f * ((a0.x + a0.z) + (b0.x + b0.z)) * fW - 0.5f - (float)s_qx;
-                const float my = 0.25f * ((a0.y + a0.w) + (b0.y + b0.w)) * fH - 0.5f - (float)s_qy;
-                if (mx == mx && my == my && fabsf(mx) < 64.f && fabsf(my) < 64.f) { sx = mx; sy = my; sn = 1.f; }
-                if constexpr (!FUSED) {
-                    const float ox_ = (float)s_qx + 0.5f, oy_ = (float)s_qy + 0.5f, rr = MSDA_PROBE_RADIUS;
-                    snear = (float)((fabsf(a0.x * fW - ox_) < rr && fabsf(a0.y * fH - oy_) < rr) + (fabsf(a0.z * fW - ox_) < rr && fabsf(a0.w * fH - oy_) < rr) +
-                                    (fabsf(b0.x * fW - ox_) < rr && fabsf(b0.y * fH - oy_) < rr) + (fabsf(b0.z * fW - ox_) < rr && fabsf(b0.w * fH - oy_) < rr));
-                    scnt = 4.f;
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                sx += __shfl_xor(sx, o, 64);
-                sy += __shfl_xor(sy, o, 64);
-                sn += __shfl_xor(sn, o, 64);
-                if constexpr (!FUSED) {
-                    snear += __shfl_xor(snear, o, 64);
-                    scnt += __shfl_xor(scnt, o, 64);
-                }
-            }
-            const float tx_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sx)));
-            const float ty_ = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sy)));
-            const float tn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
-            if (tn > 0.f) {
-                shx = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf(tx_ / tn)));
-                shy = max(-MSDA_PROBE_MAXSHIFT, min(MSDA_PROBE_MAXSHIFT, (int)rintf(ty_ / tn)));
-            }
-            if constexpr (!FUSED) {
-                const float tl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, snear)));
-                const float tc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scnt)));
-                standdown = (opts & 1) && tl * (float)MSDA_PROBE_NEAR_DIV < tc;
-            }
+            static_assert(TH == MSDA_SAMPLE_TH && TW == MSDA_SAMPLE_TW, "the sampling kernels repeat this tile's sample (msda_dispatch.h)");
+            const bool have = s_qy < Hq && s_qx < Wq;
+            float4 a0 = make_float4(0, 0, 0, 0), b0 = a0, w0;
+            if (have) fetch((int64_t)b * S + lsi[0] + (int64_t)s_qy * Wq + s_qx, b, head, 0, a0, b0, w0);   // (level 0: msda_dispatch.h)
+            bool far;
+            msda_job_sample(a0, b0, have, s_qx, s_qy, fW, fH, shx, shy, far);
+            standdown = !FUSED && (opts & 1) && far;
         }
         if (standdown) {
             // far-flung taps (e.g. uniformly random locations): this unit's (cell, camera) items through the lane-group body,
@@ -310,7 +273,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                 const int64_t q = ok ? (int64_t)b * S + lsi[c] + (int64_t)y_ * Wq + x_ : -1;
                 // (lanes without an item pass an index past the end: they stay converged with their group and store nothing)
                 const int64_t idx = ok ? (q * M + head) * D + cg : (int64_t)B * S * M * D + cg;
-                msda_bwd_lanes_body<float, 1, D, true, DOTS>(idx, go, value, shapes, lsi, loc, aw, B, S, M, D, L, S, P, grad_value,
+                // (all three gradients, also in the grad_value-only variant: the sampling kernel skips such tiles)
+                msda_bwd_lanes_body<float, 1, D, true, true>(idx, go, value, shapes, lsi, loc, aw, B, S, M, D, L, S, P, grad_value,
                                                              grad_loc, grad_aw, l_first, l_last);
             }
             continue;

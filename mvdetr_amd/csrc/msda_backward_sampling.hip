@@ -19,7 +19,6 @@
 #include "common.h"
 #include "msda_dispatch.h"
 #include "msda_tile.h"
-#include "msda_backward_lanes.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -147,28 +146,16 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
         if (local_hits) {
             msda_probe_shift(local_hits, head, shx, shy);     // (the probe launch of rounds 2-4's callers)
         } else {
-            // no probe: the job's own sample -- camera 0's taps of the tile's 32 cells at level 0 (both half lanes of a cell
-            // carry the same values) -- gives the shift and says whether the windows are worth staging at all
-            const int s_qi = lane >> 1, s_qy = Y0 + s_qi / TW, s_qx = X0 + s_qi % TW;
+            // no probe (round 5): the sample of the grad_value kernel's tile this job lies in (msda_dispatch.h) gives the
+            // window shift and says whether that kernel has taken the tile's sampling gradients along (far-flung taps)
+            const int sY0 = Y0 / MSDA_SAMPLE_TH * MSDA_SAMPLE_TH, sX0 = X0 / MSDA_SAMPLE_TW * MSDA_SAMPLE_TW;
+            const int s_qy = sY0 + lane / MSDA_SAMPLE_TW, s_qx = sX0 + lane % MSDA_SAMPLE_TW;
             const bool have = s_qy < Hq && s_qx < Wq;
             const float *lp = loc + ((((int64_t)b * S + lsi[0] + (have ? (int64_t)s_qy * Wq + s_qx : 0)) * M + head) * L) * P * 2;
             const float4 a0 = *reinterpret_cast<const float4 *>(lp), b0 = *reinterpret_cast<const float4 *>(lp + 4);
             bool far;
             msda_job_sample(a0, b0, have, s_qx, s_qy, fW, fH, shx, shy, far);
-            if (far) {
-                // far-flung taps: this job's (cell, camera) items through the lane-group body, sampling gradients only
-                const int items = TH * TW * L * D;
-                for (int it = tid; it < (items + RS_THREADS - 1) / RS_THREADS * RS_THREADS; it += RS_THREADS) {
-                    const int cg = it % D, ci = (it / D) % (TH * TW), c = it / (D * TH * TW);
-                    const int y_ = Y0 + ci / TW, x_ = X0 + ci % TW;
-                    const bool ok = it < items && y_ < Hq && x_ < Wq;
-                    const int64_t qq = ok ? (int64_t)b * S + lsi[c] + (int64_t)y_ * Wq + x_ : -1;
-                    const int64_t idx = ok ? (qq * M + head) * D + cg : (int64_t)B * S * M * D + cg;
-                    msda_bwd_lanes_body<float, 1, D, false>(idx, go, value, shapes, lsi, loc, aw, B, S, M, D, L, S, P, nullptr,
-                                                            grad_loc, grad_aw);
-                }
-                continue;
-            }
+            if (far) continue;
         }
         const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
@@ -316,26 +303,16 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
         if (local_hits) {
             msda_probe_shift(local_hits, head, shx, shy);     // (the probe launch of rounds 2-4's callers)
         } else {
-            // no probe: the job's own sample (see msda_bwd_sampling_resident)
-            const int s_qi = lane >> 1, s_qy = Y0 + s_qi / TW, s_qx = X0 + s_qi % TW;
+            // no probe (round 5): the sample of the grad_value kernel's tile this job lies in (msda_dispatch.h) gives the
+            // window shift and says whether that kernel has taken the tile's sampling gradients along (far-flung taps)
+            const int sY0 = Y0 / MSDA_SAMPLE_TH * MSDA_SAMPLE_TH, sX0 = X0 / MSDA_SAMPLE_TW * MSDA_SAMPLE_TW;
+            const int s_qy = sY0 + lane / MSDA_SAMPLE_TW, s_qx = sX0 + lane % MSDA_SAMPLE_TW;
             const bool have = s_qy < Hq && s_qx < Wq;
             const float *lp = loc + ((((int64_t)b * S + lsi[0] + (have ? (int64_t)s_qy * Wq + s_qx : 0)) * M + head) * L) * P * 2;
             const float4 a0 = *reinterpret_cast<const float4 *>(lp), b0 = *reinterpret_cast<const float4 *>(lp + 4);
             bool far;
             msda_job_sample(a0, b0, have, s_qx, s_qy, fW, fH, shx, shy, far);
-            if (far) {
-                const int items = TH * TW * L * D;
-                for (int it = tid; it < (items + RS_THREADS - 1) / RS_THREADS * RS_THREADS; it += RS_THREADS) {
-                    const int cg = it % D, ci = (it / D) % (TH * TW), c = it / (D * TH * TW);
-                    const int y_ = Y0 + ci / TW, x_ = X0 + ci % TW;
-                    const bool ok = it < items && y_ < Hq && x_ < Wq;
-                    const int64_t qq = ok ? (int64_t)b * S + lsi[c] + (int64_t)y_ * Wq + x_ : -1;
-                    const int64_t idx = ok ? (qq * M + head) * D + cg : (int64_t)B * S * M * D + cg;
-                    msda_bwd_lanes_body<float, 1, D, false>(idx, go, value, shapes, lsi, loc, aw, B, S, M, D, L, S, P, nullptr,
-                                                            grad_loc, grad_aw);
-                }
-                continue;
-            }
+            if (far) continue;
         }
         const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);

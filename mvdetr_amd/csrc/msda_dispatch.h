@@ -29,7 +29,7 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
                       const float *loc, const float *aw, int B, int S, int M, int D, int L, int Lq,
                       int P, float *out, const int *local_hits);
 // false when the kernel that takes the call decides per tile, inside the launch, whether to stage windows (msda_fwd_group2)
-bool msda_forward_tile_wants_probe(int S, int M, int D, int L);
+bool msda_forward_tile_wants_probe(int B, int S, int M, int D, int L);
 inline int msda_forward_tile(hipStream_t, const double *, const int64_t *, const int64_t *,
                              const double *, const double *, int, int, int, int, int, int, int,
                              double *, const int *)
@@ -54,6 +54,7 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
 int msda_backward_value_tile(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                              const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
                              float *grad_value, float *grad_loc, float *grad_aw, const int *local_hits);
+bool msda_backward_value_tile_fits(int S, int M, int D, int L);
 // the same through token-major windows (msda_backward_value_tok.hip): what msda_backward_value_tile[_fused] dispatch to
 int msda_backward_value_tok(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                             const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int D, int L,
@@ -117,6 +118,12 @@ __device__ __forceinline__ void msda_probe_shift(const int *__restrict__ probe, 
 // MSDA_PROBE_RADIUS pixels of their own cell (`far`: the job computes its taps in the lane-group formulation instead of
 // staging windows).  All waves see the same data and do the same arithmetic: the results are workgroup-uniform without LDS
 // or a barrier.  la / lb: the lane's four normalised (x, y) locations; have: the lane holds a cell of the map.
+// The tile whose sample decides: the grad_value kernel's (msda_backward_onepass.hip) -- the sampling kernels' 4 x 8 jobs are
+// nested in it and repeat ITS sample (first 64 cells, camera 0, level 0), so that both kernels of a backward agree on which
+// (tile, head) stand down: the grad_value kernel then computes all three gradients of such a tile in the lane-group
+// formulation and the sampling kernel skips it.
+#define MSDA_SAMPLE_TH 4
+#define MSDA_SAMPLE_TW 16
 __device__ __forceinline__ void msda_job_sample(const float4 &la, const float4 &lb, bool have, int qx, int qy, float fW, float fH,
                                                 int &shx, int &shy, bool &far)
 {

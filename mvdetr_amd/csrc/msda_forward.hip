@@ -128,7 +128,7 @@ static int forward_entry(void *stream, const T *value, const int64_t *shapes, co
             // (6 / 7 equal levels: msda_fwd_group2 looks at every tile's own taps and stands down job by job -- no probe
             // kernel, no scratch allocation in front of the forward)
             int *hits = nullptr;
-            if (msda_fwd_impl_knob() == 0 && msda_forward_tile_wants_probe(S, M, D, L) &&
+            if (msda_fwd_impl_knob() == 0 && msda_forward_tile_wants_probe(B, S, M, D, L) &&
                 hipMallocAsync(reinterpret_cast<void **>(&hits), MSDA_PROBE_INTS * sizeof(int), st) != hipSuccess)
                 hits = nullptr;
             int rc = hits ? msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits) : 0;
@@ -266,7 +266,8 @@ int mvdetr_msda_fused_train_supported(int batch, int spatial_size, int num_heads
     // 32-channel heads, 4 points, queries = tokens, 32-bit offsets inside one batch element
     if (!msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, true, 0, num_levels)) return 0;
     if (!(num_levels == 6 || num_levels == 7) || channels != 16 || !msda_group_supported(channels, num_levels)) return 0;
-    return (int64_t)spatial_size * num_heads * num_levels * num_point * 3 < ((int64_t)1 << 30) ? 1 : 0;
+    // (the whole raw tensor, all batch elements: msda_group_fits)
+    return (int64_t)batch * spatial_size * num_heads * num_levels * num_point * 3 < ((int64_t)1 << 30) ? 1 : 0;
 }
 
 int mvdetr_msda_forward_fused_train_f32(void *stream, const float *value, const int64_t *spatial_shapes,

@@ -28,12 +28,12 @@ bool msda_group_supported(int D, int L)
 }
 
 // options of a launch, from the environment (read once): MVDETR_MSDA_WINDOW_SHIFT=0 keeps the fused kernels' windows centred
-// on the tile, MVDETR_MSDA_JOBMAP=band|blocks chooses how the jobs are dealt to the XCDs (A/B knobs)
+// on the tile (A/B knob); the jobs are dealt to the XCDs as 2-D blocks of the tile grid (GROUP_OPT_BLOCKS: 566 -> 314 MB of
+// memory-side traffic per launch against bands of the job list, round 4)
 static int group_opts(int fused)
 {
     static const bool no_shift = [] { const char *e = getenv("MVDETR_MSDA_WINDOW_SHIFT"); return e && e[0] == '0'; }();
-    static const bool blocks = [] { const char *e = getenv("MVDETR_MSDA_JOBMAP"); return !(e && !strcmp(e, "band")); }();
-    return ((fused && no_shift) ? GROUP_OPT_NO_SHIFT : 0) | (blocks ? GROUP_OPT_BLOCKS : 0);
+    return ((fused && no_shift) ? GROUP_OPT_NO_SHIFT : 0) | GROUP_OPT_BLOCKS;
 }
 
 #ifdef MVDETR_GROUP_TRACE

@@ -88,15 +88,6 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
     return (int)hipGetLastError();
 }
 
-static bool narrow_slices()
-{
-    static const bool v = [] {
-        const char *e = getenv("MVDETR_MSDA_TILE_SLICE");      // tuning knob; measured: 128-byte slices win
-        return e && !strcmp(e, "64");
-    }();
-    return v;
-}
-
 #define TILE_ARGS st, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out, local_hits
 
 template <int FUSED>
@@ -104,20 +95,20 @@ static int dispatch_tile(hipStream_t st, const float *value, const int64_t *shap
                          const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
                          QueryLevels qr, int B, int S, int M, int D, int L, float *out, const int *local_hits = nullptr)
 {
-    const bool narrow = narrow_slices();
-    if (D == 16) return narrow ? launch_tile<CfgNarrow16, FUSED>(TILE_ARGS) : launch_tile<CfgWide16, FUSED>(TILE_ARGS);
-    if (D == 32) return narrow ? launch_tile<CfgNarrow32, FUSED>(TILE_ARGS) : launch_tile<CfgWide32, FUSED>(TILE_ARGS);
+    // (128-byte slices; 64-byte ones -- twice the workgroups per CU -- were measured slower: DESIGN 5.2)
+    if (D == 16) return launch_tile<CfgWide16, FUSED>(TILE_ARGS);
+    if (D == 32) return launch_tile<CfgWide32, FUSED>(TILE_ARGS);
     return (int)hipErrorInvalidValue;
 }
 
-static bool group2_takes(int S, int M, int D, int L, const SamplingLayout &lay)
+static bool group2_takes(int B, int S, int M, int D, int L, const SamplingLayout &lay)
 {
-    return msda_group_supported(D, L) && L <= 7 && msda_group_fits(S, M * D, lay) && !narrow_slices();
+    return msda_group_supported(D, L) && L <= 7 && msda_group_fits(B, S, M * D, lay);
 }
 
-bool msda_forward_tile_wants_probe(int S, int M, int D, int L)
+bool msda_forward_tile_wants_probe(int B, int S, int M, int D, int L)
 {
-    return !group2_takes(S, M, D, L, plain_layout(M * L * TILE_P * 2, L * TILE_P * 2, TILE_P * 2, M * L * TILE_P, L * TILE_P, TILE_P));
+    return !group2_takes(B, S, M, D, L, plain_layout(M * L * TILE_P * 2, L * TILE_P * 2, TILE_P * 2, M * L * TILE_P, L * TILE_P, TILE_P));
 }
 
 int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -127,7 +118,7 @@ int msda_forward_tile(hipStream_t st, const float *value, const int64_t *shapes,
     const SamplingLayout lay = plain_layout(M * L * P * 2, L * P * 2, P * 2, M * L * P, L * P, P);     // [.., Lq, M, L, P(, 2)]
     // camera-grouped kernel also for the public (unfused) contract: 188 vs 197 us at Wildtrack size -- the
     // reference layout re-touches every sampling_loc line in 4 level iterations, so the gain is small
-    if (msda_group_supported(D, L) && msda_group_fits(S, M * D, lay) && !narrow_slices())
+    if (msda_group_supported(D, L) && msda_group_fits(B, S, M * D, lay))
         return msda_forward_group(st, value, shapes, lsi, loc, aw, nullptr, 0, 0, lay, B, S, M, D, L, out, local_hits,
                                   /*standdown=*/msda_fwd_impl_knob() == 0);
     return dispatch_tile<0>(st, value, shapes, lsi, loc, aw, nullptr, 0, lay, QueryLevels{0, L, S}, B, S, M, D, L, out, local_hits);
@@ -166,7 +157,7 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     // A query-sharded call (a rank's own cameras as queries, mvdetr_amd/dist.py) has too few query levels per
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
-    if (all_levels && msda_group_supported(D, L) && msda_group_fits(S, M * D, lay) && !narrow_slices())
+    if (all_levels && msda_group_supported(D, L) && msda_group_fits(B, S, M * D, lay))
         return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
                                   M, D, L, out, nullptr, false, stats);
     if (stats) return (int)hipErrorNotSupported;            // the training entry exists where msda_fwd_group2 takes the call

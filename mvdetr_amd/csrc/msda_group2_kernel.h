@@ -162,10 +162,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
         const unsigned vo_l = (cell * (unsigned)lay.q_l + (unsigned)lay.head_l(head)) * 4u;
         const unsigned vo_w = (cell * (unsigned)lay.q_w + (unsigned)lay.head_w(head)) * 4u;
         const unsigned vo_r = cell * (unsigned)lay.r_q * 4u;
-        // per-batch-element bases: the 32-bit scalar offsets below then only span ONE batch element's sampling data (which
-        // msda_group_fits() bounds), not b * S * q_l -- a whole-tensor base wrapped silently from 4 GiB on (B >= 6 at Wildtrack size)
-        const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(off + (int64_t)b * S * lay.q_l), 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(logit + (int64_t)b * S * lay.q_w), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(off), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(logit), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float *>(FUSED ? ref + b * ref_bstride : value), 0, 0x7fffffff, 0x00020000);
         auto cam_q = [&](int c) { return (int64_t)b * S + lsi[c]; };          // wave-uniform
@@ -173,8 +171,8 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
 
         float4 na = make_float4(0, 0, 0, 0), nb = na, nw = na, nr0 = na, nr1 = na;
         auto load_cam = [&](int c, int l) {
-            const int64_t cq = cam_q(c), cl = cq - (int64_t)b * S;       // (cl: inside the batch element)
-            const unsigned so_l = (unsigned)(cl * lay.q_l + l * lay.l_l) * 4u, so_w = (unsigned)(cl * lay.q_w + l * lay.l_w) * 4u;
+            const int64_t cq = cam_q(c);
+            const unsigned so_l = (unsigned)(cq * lay.q_l + l * lay.l_l) * 4u, so_w = (unsigned)(cq * lay.q_w + l * lay.l_w) * 4u;
             na = buf_load4(rs_l, vo_l, so_l);
             nb = buf_load4(rs_l, vo_l + 16u, so_l);
             nw = buf_load4(rs_w, vo_w, so_w);
@@ -320,7 +318,9 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
         for (int k = 0; k < NV; ++k) choff[k] = (k ^ rot) << 2;
 
         for (int l = 0; l < L; ++l) {
-            __syncthreads();                                  // everyone is done reading the old window
+            // everyone is done reading the old window (an LDS-only barrier: the sampling data requested above stays in flight
+            // and overlaps the window copy; __syncthreads() waited for it here, then for the copy)
+            lds_barrier();
             {
                 // LDS-DMA window copy (see msda_fwd_group); its per-lane constants are re-derived here from an opaque copy
                 // of the thread index so that they do not stay in registers through the tap stream

@@ -41,8 +41,6 @@ template <int D_, int SLICE_, int TH_, int TW_, int R_, int THREADS_ = TH_ * TW_
 // waves to hide LDS and global latency behind, at the price of duplicating the per-tap address math).
 using CfgWide16 = TileCfg<16, 32, 8, 16, 6>;
 using CfgWide32 = TileCfg<32, 32, 8, 16, 6>;
-using CfgNarrow16 = TileCfg<16, 16, 8, 16, 6>;
-using CfgNarrow32 = TileCfg<32, 16, 8, 16, 6>;
 
 // Where element (query, head, level) of the sampling locations / weights starts, in floats:
 //     query * q + (head / hps) * s + (head % hps) * h + level * l
@@ -72,12 +70,14 @@ struct QueryLevels {
 
 // camera-grouped fused forward (msda_forward_group.hip)
 bool msda_group_supported(int D, int L);
-// its per-lane addresses are 32-bit float offsets from per-batch, per-camera bases: one batch element's sampling tensors,
-// reference points and output must each stay below 2^32 bytes (anything larger runs the tile kernel: 64-bit addresses)
-inline bool msda_group_fits(int S, int row, const SamplingLayout &lay)
+// its per-lane addresses are 32-bit float offsets from per-batch, per-camera bases: one batch element's reference points and
+// output must each stay below 2^32 bytes -- and the WHOLE sampling tensors (all B elements), because msda_fwd_group2 folds the
+// batch index into the 32-bit scalar offset of one whole-tensor buffer descriptor (per-batch descriptors cost the headline
+// instantiation its zero-scratch build: ADVICE r04).  Anything larger runs the tile kernel: 64-bit addresses.
+inline bool msda_group_fits(int B, int S, int row, const SamplingLayout &lay)
 {
     const int64_t lim = (int64_t)1 << 30;                   // floats
-    return (int64_t)S * lay.q_l < lim && (int64_t)S * lay.q_w < lim && (int64_t)S * lay.r_q < lim && (int64_t)S * row < lim;
+    return (int64_t)B * S * lay.q_l < lim && (int64_t)B * S * lay.q_w < lim && (int64_t)S * lay.r_q < lim && (int64_t)S * row < lim;
 }
 // fused: 0 = final locations / weights (ref unused), 1 = raw + reference points [.., Lq, L, P, 2], 2 = raw + one
 // reference point per (query, level) [.., Lq, L, 2]

@@ -949,10 +949,14 @@ static int warp_bwd_impl()
 // Not for HIP graph capture (the allocation would be captured once and the pointer reused across replays): capturing callers
 // use the two-step form (mvdetr_warp_backward_plan_* into their own buffer).  Streams that have been destroyed leave their
 // entry behind; mvdetr_warp_release_scratch() drops every entry (call it when no warp backward is in flight).
-struct WarpScratchEntry { char *ptr; size_t size; };
+// (tag, key): the caller's version tag and the shapes of the plan the scratch currently holds (0: none)
+struct WarpScratchEntry { char *ptr; size_t size; uint64_t tag; int64_t key[6]; };
 static std::mutex g_warp_scratch_mu;
 static std::map<std::pair<int, hipStream_t>, WarpScratchEntry> g_warp_scratch;
-static char *warp_stream_scratch(hipStream_t st, size_t bytes, hipError_t &rc)
+// `tag` != 0: the caller's promise that calls with the same tag (on this device and stream, with the same shapes) have the same
+// matrices; `reuse` is set when the scratch already holds the plan of such a call -- the geometry pass is then skipped.
+static char *warp_stream_scratch(hipStream_t st, size_t bytes, hipError_t &rc, uint64_t tag = 0, const int64_t *key = nullptr,
+                                 bool *reuse = nullptr)
 {
     using Entry = WarpScratchEntry;
     std::mutex &mu = g_warp_scratch_mu;
@@ -961,14 +965,22 @@ static char *warp_stream_scratch(hipStream_t st, size_t bytes, hipError_t &rc)
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
     Entry &e = cache[{dev, st}];
+    if (reuse) *reuse = false;
     if (e.size < bytes) {
         if (e.ptr) (void)hipFreeAsync(e.ptr, st);              // (after the work already queued on this stream)
         e.ptr = nullptr;
         e.size = 0;
+        e.tag = 0;
         const size_t want = bytes + bytes / 4;
         rc = hipMallocAsync(reinterpret_cast<void **>(&e.ptr), want, st);
         if (rc != hipSuccess) { e.ptr = nullptr; return nullptr; }
         e.size = want;
+    }
+    if (tag && key && e.tag == tag && !memcmp(e.key, key, sizeof(e.key))) {
+        if (reuse) *reuse = true;
+    } else {
+        e.tag = key ? tag : 0;                               // (an untagged call overwrites the plan: forget the tag)
+        if (key) memcpy(e.key, key, sizeof(e.key));
     }
     return e.ptr;
 }
@@ -1056,25 +1068,35 @@ static int warp_bwd_planned_launch(hipStream_t st, const T *grad_dst, const T *M
 
 template <typename T>
 static int warp_bwd_gather_launch(hipStream_t st, const T *grad_dst, const T *Mv, int N, int C, int h, int w, int H,
-                                  int W, int nearest, T *grad_src)
+                                  int W, int nearest, T *grad_src, uint64_t tag)
 {
     int lgG, cgroups;
     int64_t wgs;
     if (!warp_gather_shapes<T>(N, C, h, w, H, W, lgG, cgroups, wgs)) return (int)hipErrorNotSupported;
     // the plan of this call in stream-ordered scratch (kept per stream between calls: hipMallocAsync + hipFreeAsync cost the
-    // host ~10 us per call, more than the launches); callers whose matrices do not change build it once instead
-    // (mvdetr_warp_backward_plan_*, mvdetr_warp_perspective_backward_planned_*)
+    // host ~10 us per call, more than the launches).  A caller-supplied version tag of the matrices lets consecutive calls
+    // reuse the plan itself (mvdetr_warp_perspective_backward_tagged_*): the gather is then the only launch.  Callers who own
+    // a plan buffer use mvdetr_warp_backward_plan_* / mvdetr_warp_perspective_backward_planned_* instead.
     hipError_t rc = hipSuccess;
-    char *scratch = warp_stream_scratch(st, warp_plan_layout(N, h, w, H, W).total(), rc);
+    const char *ge = getenv("MVDETR_WARP_BWD_GEOMETRY"), *he = getenv("MVDETR_WARP_BWD_HEAVY");
+    const int64_t key[6] = {N, h, w, ((int64_t)H << 32) | (unsigned)W, (int64_t)sizeof(T),
+                            (int64_t)(ge && !strcmp(ge, "clip")) | ((int64_t)(he ? atoi(he) + 1 : 0) << 8)};
+    bool reuse = false;
+    char *scratch = warp_stream_scratch(st, warp_plan_layout(N, h, w, H, W).total(), rc, tag, key, &reuse);
     if (!scratch) return (int)rc;
-    const int r1 = warp_bwd_plan_launch<T>(st, Mv, N, h, w, H, W, scratch);
-    if (r1) return r1;
+    if (!reuse) {
+        const int r1 = warp_bwd_plan_launch<T>(st, Mv, N, h, w, H, W, scratch);
+        if (r1) {
+            (void)warp_stream_scratch(st, 0, rc, 0, key, nullptr);      // (no plan was built: forget the tag)
+            return r1;
+        }
+    }
     return warp_bwd_planned_launch<T>(st, grad_dst, Mv, scratch, N, C, h, w, H, W, nearest, grad_src);
 }
 
 template <typename T>
 static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int N, int C, int h, int w,
-                      int H, int W, int nhwc, T *o)
+                      int H, int W, int nhwc, T *o, uint64_t tag = 0)
 {
     if (N < 0 || C < 0 || h <= 0 || w <= 0 || H < 0 || W < 0) return (int)hipErrorInvalidValue;
     if (nhwc & ~7) return (int)hipErrorInvalidValue;
@@ -1119,7 +1141,7 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
             return (int)hipGetLastError();
         }
         if (!warp_bwd_impl()) {
-            const int rc = warp_bwd_gather_launch<T>(st, a, Mv, N, C, h, w, H, W, nearest, o);
+            const int rc = warp_bwd_gather_launch<T>(st, a, Mv, N, C, h, w, H, W, nearest, o, tag);
             if (rc != (int)hipErrorNotSupported) {
                 g_warp_last_kernel = "warp_bwd_gather";
                 return rc;
@@ -1274,6 +1296,21 @@ int mvdetr_warp_perspective_backward_f32(void *stream, const float *grad_dst, co
 {
     return mvdetr::warp_entry<float>(true, stream, grad_dst, M, n, channels, src_h, src_w, dst_h, dst_w,
                                      layout_nhwc, grad_src);
+}
+
+int mvdetr_warp_perspective_backward_tagged_f32(void *stream, const float *grad_dst, const float *M, int n, int channels,
+                                                int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                uint64_t matrices_tag, float *grad_src)
+{
+    return mvdetr::warp_entry<float>(true, stream, grad_dst, M, n, channels, src_h, src_w, dst_h, dst_w, layout_nhwc, grad_src,
+                                     matrices_tag);
+}
+int mvdetr_warp_perspective_backward_tagged_f64(void *stream, const double *grad_dst, const double *M, int n, int channels,
+                                                int src_h, int src_w, int dst_h, int dst_w, int layout_nhwc,
+                                                uint64_t matrices_tag, double *grad_src)
+{
+    return mvdetr::warp_entry<double>(true, stream, grad_dst, M, n, channels, src_h, src_w, dst_h, dst_w, layout_nhwc, grad_src,
+                                      matrices_tag);
 }
 
 int64_t mvdetr_warp_backward_plan_bytes(int n, int channels, int src_h, int src_w, int dst_h, int dst_w, int elem_size)

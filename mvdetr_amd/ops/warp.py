@@ -19,9 +19,16 @@ from .. import _lib
 DST_NHWC, SRC_NHWC, NEAREST = 1, 2, 4          # bits of the C ABI's layout_nhwc argument (include/mvdetr_ops.h)
 
 
-def _launch(name, a, M, n, c, h, w, H, W, layout, out, plan=None):
+def _launch(name, a, M, n, c, h, w, H, W, layout, out, plan=None, tag=0):
     """One C-ABI call: ``name`` = "forward" | "backward"; with ``plan`` (backward only) the two-step gradient's second step
-    (mvdetr_warp_perspective_backward_planned_*)."""
+    (mvdetr_warp_perspective_backward_planned_*); with ``tag`` != 0 (backward only) the one-call gradient with a version tag
+    of the matrices (mvdetr_warp_perspective_backward_tagged_*: the library reuses its own plan while the tag stays)."""
+    if tag and plan is None and a.is_cuda and name == "backward":
+        with torch.cuda.device(a.device):
+            rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_backward_tagged_{_lib.suffix(a.dtype)}")(
+                _lib.current_stream_ptr(a.device), a.data_ptr(), M.data_ptr(), n, c, h, w, H, W, layout, int(tag), out.data_ptr())
+        _lib.check(rc, "warp_perspective_backward_tagged")
+        return
     if plan is not None:
         with torch.cuda.device(a.device):
             rc = getattr(_lib.lib(), f"mvdetr_warp_perspective_backward_planned_{_lib.suffix(a.dtype)}")(
@@ -125,6 +132,12 @@ class _BackwardPlans:
     def clear(self):
         with self.lock:
             self.parts.clear()
+
+    @property
+    def entries(self):
+        """Every cached (M, version, key, plan), most recent first within its (device, stream) partition (tests, bench)."""
+        with self.lock:
+            return [e for part in self.parts.values() for e in part]
 
 
 _plans = _BackwardPlans()

@@ -145,3 +145,14 @@ def test_product_package_never_imports_the_oracle():
     for path in pathlib.Path(ROOT, "mvdetr_amd", "csrc").glob("*"):
         if path.suffix in (".hip", ".h"):
             assert "oracle" not in path.read_text(), path
+
+
+def test_fused_train_support_bounds_the_whole_raw_tensor(built):
+    """msda_fwd_group2 folds the batch index into a 32-bit scalar offset of ONE whole-tensor buffer descriptor, so the
+    camera-grouped kernels (and the training pair built on them) only take calls whose WHOLE raw tensor stays below 4 GiB; larger
+    batches must be refused here (and run the 64-bit tile kernel through the inference entry)."""
+    lib = built.lib()
+    S, M, D, L, P = 75600, 8, 16, 7, 4
+    assert lib.mvdetr_msda_fused_train_supported(1, S, M, D, L, S, P) == 1
+    assert lib.mvdetr_msda_fused_train_supported(21, S, M, D, L, S, P) == 1       # 21 x 203 MB = 4.27e9 B < 2^32
+    assert lib.mvdetr_msda_fused_train_supported(22, S, M, D, L, S, P) == 0       # 4.47e9 B

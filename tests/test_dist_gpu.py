@@ -89,3 +89,25 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_process_frame():
         p.join(timeout=120)
     for rank, ok, msg in results:
         assert ok, f"rank {rank}: {msg}"
+
+
+def test_bench_two_ranks_view_sharded_replicated_line():
+    """`bench.py --gpus 2 --parallel views --encoder replicated` on the one GPU of the test box (gloo, ranks share the device):
+    the line must say so -- 2 ranks, parallelism views2-replicated, oversubscribed, no scaling claim -- and rank 0's unsharded
+    calibration frame must have run first."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--parallel", "views", "--encoder",
+                          "replicated", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-rooflines"],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["parallelism"] == "views2-replicated"
+    assert line["config"]["ranks"] == 2 and len(line["config"]["rank_placement"]) == 2
+    if line["config"]["distinct_devices"] < 2:       # (the test box has one GPU: the ranks share it)
+        assert line["config"]["oversubscribed"] is True and line["scaling"] is None and line["n_gpus"] == 1
+    assert line["config"]["gemm_tuning_shared_from_rank0"] in (True, False)      # rank 0 went first (False: sharing failed, said so)
+    assert line["value"] > 0

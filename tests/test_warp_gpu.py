@@ -501,7 +501,7 @@ def test_planned_backward_equals_the_one_call_entry_and_the_plan_is_reused(warp)
     go = torch.randn(7, 120, 360, 128, generator=torch.Generator().manual_seed(6)).cuda()
     plain = _bwd_cl(go, M, 7, 128, 90, 160)
     assert _last_kernel() == "warp_bwd_gather"
-    warp_mod._plans.entries.clear()
+    warp_mod._plans.clear()
     grads = []
     for _ in range(3):
         leaf = src.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
@@ -522,6 +522,40 @@ def test_planned_backward_equals_the_one_call_entry_and_the_plan_is_reused(warp)
     leaf = src.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
     warp(leaf, M2, (120, 360), channels_last_out=True).backward(go)
     assert torch.equal(leaf.grad.permute(0, 2, 3, 1), _bwd_cl(go, M2, 7, 128, 90, 160))
+
+
+def test_tagged_backward_reuses_the_librarys_plan_and_forgets_it_when_it_must(warp):
+    """ABI 12: mvdetr_warp_perspective_backward_tagged_* -- the one-call entry with a caller-supplied version tag of the
+    matrices.  Same tag: the geometry in the per-(device, stream) scratch is reused (the gather alone is launched); another tag,
+    other shapes or an untagged call in between: it is rebuilt.  Every result equals the untagged entry bit for bit."""
+    from mvdetr_amd.ops import warp as warp_mod
+    n, c, h, w, H, W = 7, 128, 90, 160, 120, 360
+    M1 = wildtrack_mats(None).float().cuda().contiguous()
+    M2 = wildtrack_mats(4).float().cuda().contiguous()
+    go = torch.randn(n, H, W, c, generator=torch.Generator().manual_seed(8)).cuda()
+
+    def run(M, tag):
+        gs = torch.empty(n, h, w, c, device="cuda")
+        warp_mod._launch("backward", go, M, n, c, h, w, H, W, 3, gs, tag=tag)
+        return gs
+    want1, want2 = run(M1, 0), run(M2, 0)
+    assert torch.equal(run(M1, 5), want1)                      # builds the plan, remembers tag 5
+    assert torch.equal(run(M1, 5), want1)                      # reuses it
+    assert torch.equal(run(M1, 5), want1)
+    assert torch.equal(run(M2, 6), want2)                      # another tag: rebuilt for the other matrices
+    assert torch.equal(run(M2, 6), want2)
+    assert torch.equal(run(M1, 0), want1)                      # an untagged call overwrites the scratch's plan ...
+    assert torch.equal(run(M2, 6), want2)                      # ... so tag 6 must not be trusted any more
+    # other shapes under the same tag: a different key, rebuilt
+    go2 = torch.randn(n, 60, 180, c, generator=torch.Generator().manual_seed(9)).cuda()
+    gs_a, gs_b = torch.empty(n, h, w, c, device="cuda"), torch.empty(n, h, w, c, device="cuda")
+    warp_mod._launch("backward", go2, M2, n, c, h, w, 60, 180, 3, gs_a, tag=6)
+    warp_mod._launch("backward", go2, M2, n, c, h, w, 60, 180, 3, gs_b)
+    assert torch.equal(gs_a, gs_b)
+    # and it is faster than rebuilding: the scans kernel is gone from the call (loose bound: any gain at all)
+    t_tag = _time_us(lambda: run(M1, 77))
+    t_plain = _time_us(lambda: run(M1, 0))
+    assert t_tag < t_plain, (t_tag, t_plain)
 
 
 def test_backward_cost_is_bounded_with_the_horizon_in_view(warp):
