@@ -79,6 +79,40 @@ __device__ __forceinline__ Footprint<T> footprint(T h, T w, int H, int W) {
     return f;
 }
 
+// The same footprint from a position already split into its integer and fractional part (see fused_px).
+template <typename T>
+__device__ __forceinline__ Footprint<T> footprint_split(T fy, T wy1, T fx, T wx1, int H, int W) {
+    Footprint<T> f;
+    f.y0 = (int)fy;
+    f.x0 = (int)fx;
+    f.wy1 = wy1;
+    f.wx1 = wx1;
+    f.wy0 = T(1) - wy1;
+    f.wx0 = T(1) - wx1;
+    f.vy0 = f.y0 >= 0 && f.y0 < H;
+    f.vy1 = f.y0 + 1 >= 0 && f.y0 + 1 < H;
+    f.vx0 = f.x0 >= 0 && f.x0 < W;
+    f.vx1 = f.x0 + 1 >= 0 && f.x0 + 1 < W;
+    return f;
+}
+
+// Pixel coordinate of a tap of the FUSED training backward, ref * size - 0.5 + off (reference point normalised, offset in pixels),
+// in two parts: `fl` = its floor (an integer-valued float), `frac` = the bilinear weight of the far corner.  Formed as ONE fp32
+// number -- (ref + off / size) * size - 0.5, the module's own arithmetic -- a position near 143.5 carries half an ulp = 7.6e-6 px
+// of rounding, which a blend of four <grad_out, value> dots of +-19 turns into 3e-4 of grad_attn_weight (round 4's soak).  Here the
+// reference point's own texel c = rint(ref * size - 0.5) is split off exactly (fma), so the roundings that remain happen at the
+// magnitude of the offset (a few pixels: <= 5e-7 px).  `x` = fl + frac is the coarse position for window / image tests.
+__device__ __forceinline__ void fused_px(float ref, float off, float size, float &x, float &fl, float &frac)
+{
+    const float c = rintf(__fmaf_rn(ref, size, -0.5f));
+    const float r = __fmaf_rn(ref, size, -(c + 0.5f));
+    const float t = r + off;
+    const float ft = floorf(t);
+    fl = c + ft;
+    frac = t - ft;
+    x = fl + frac;
+}
+
 // A 16-byte global load that yields zeros when `ok` is false, without a branch and without touching `p` then: the address
 // is replaced by `safe` (any readable address) and the VALUE is selected afterwards.  (`ok ? *p : zero` makes hipcc select
 // between the global pointer and a zero it puts on the stack -- a flat load and scratch in kernels that need none.)

@@ -78,8 +78,6 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
     }
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
     const float fW = (float)Wq, fH = (float)Hq;
-    const float iw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.f / fW)));
-    const float ih = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.f / fH)));
     const int tcols = (Wq + TW - 1) / TW, trows = (Hq + TH - 1) / TH, per_level = trows * tcols;
     const int jobs = per_level * HS * B, jobs8 = (jobs + 7) / 8;
     const int Lq = S;                                         // queries = tokens
@@ -320,15 +318,17 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
                         {
                             const float lx = p == 0 ? la.x : p == 1 ? la.z : p == 2 ? lb.x : lb.z;
                             const float ly = p == 0 ? la.y : p == 1 ? la.w : p == 2 ? lb.y : lb.w;
-                            float x = (ra.x + lx * iw) * fW - 0.5f, y = (ra.y + ly * ih) * fH - 0.5f;
+                            // (position in two parts, common.h: the corner weights keep 5e-7 px where one fp32 number has 8e-6)
+                            float x, y, fx, fy, wx1, wy1;
+                            fused_px(ra.x, lx, fW, x, fx, wx1);
+                            fused_px(ra.y, ly, fH, y, fy, wy1);
                             const bool in = fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1);
-                            x = in ? x : cx;
-                            y = in ? y : cy;
+                            fx = in ? fx : floorf(cx);       // (finite stand-ins: a NaN position must not reach the addresses)
+                            fy = in ? fy : floorf(cy);
                             mlevel |= in ? 0u : (1u << (c * P + p));
-                            const float fx = floorf(x), fy = floorf(y);
                             const int ix = (int)fx - ox, iy = (int)fy - oy;
                             float *w = tw[(c * P + p) & 1];
-                            w[0] = x - fx; w[1] = y - fy; w[2] = in ? aws[p] : 0.f;
+                            w[0] = in ? wx1 : 0.f; w[1] = in ? wy1 : 0.f; w[2] = in ? aws[p] : 0.f;
                             const float *pw = wbase + __mul24(iy * WW + ix, SLICE);
                             p0 = in ? pw : zbase;
                         }
@@ -366,11 +366,13 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
                     while (mm) {
                         const int pp = __ffs((int)mm) - 1;
                         mm &= mm - 1;
-                        const float x = (rp[0] + lp[pp * 2] * iw) * fW - 0.5f, y = (rp[1] + lp[pp * 2 + 1] * ih) * fH - 0.5f;
+                        float x, y, flx, fly, frx, fry;
+                        fused_px(rp[0], lp[pp * 2], fW, x, flx, frx);
+                        fused_px(rp[1], lp[pp * 2 + 1], fH, y, fly, fry);
                         const float a = __expf(wp[pp] - s.x) * s.y;
                         float dx = 0.f, dy = 0.f, da = 0.f;
                         if (y > -1.f && x > -1.f && y < fH && x < fW) {
-                            const Footprint<float> f = footprint(y, x, Hq, Wq);
+                            const Footprint<float> f = footprint_split(fly, fry, flx, frx, Hq, Wq);
                             const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * Wq + f.x0) * row;
                             const float *r1 = r0 + (int64_t)Wq * row;
                             float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;

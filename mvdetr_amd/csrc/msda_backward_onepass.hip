@@ -187,14 +187,20 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
         float2 r, st;     // fused: reference point, softmax statistics
         float4 gq, oq;    // fused: this lane's quarter of the (query, head)'s grad_out / forward output rows
     };
-    auto tap_of = [&](const TapRaw &t, float &x, float &y, float &a) {
+    // -> pixel position (x, y), its floor (fx, fy) and the far corner's weights (wx1, wy1), attention weight a
+    auto tap_of = [&](const TapRaw &t, float &x, float &y, float &fx, float &fy, float &wx1, float &wy1, float &a) {
         if constexpr (FUSED) {
-            x = op_pix(__fmaf_rn(t.o.x, iw, t.r.x), fW);
-            y = op_pix(__fmaf_rn(t.o.y, ih, t.r.y), fH);
+            // (the position in two parts, common.h: the corner weights keep 5e-7 px where ONE fp32 number has 8e-6 at x ~ 143)
+            fused_px(t.r.x, t.o.x, fW, x, fx, wx1);
+            fused_px(t.r.y, t.o.y, fH, y, fy, wy1);
             a = __expf(t.w - t.st.x) * t.st.y;
         } else {
             x = op_pix(t.o.x, fW);
             y = op_pix(t.o.y, fH);
+            fx = floorf(x);
+            fy = floorf(y);
+            wx1 = x - fx;
+            wy1 = y - fy;
             a = t.w;
         }
     };
@@ -229,14 +235,30 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
     // rare case that the guess was too small.  Every workgroup takes one contiguous range of the unit-major job list (a range
     // may begin and end inside a unit: 10,080 jobs over 512 workgroups are 19 or 20 each, where whole units would be 2 or 3
     // of 7); workgroups of one XCD take neighbouring ranges.
+    // opts bit 1: the other order, kept for A/B (MVDETR_MSDA_BWD_ORDER=spread) -- every level job on its own, dealt round-robin
+    // inside an XCD's band of the job list, so that the L level jobs of a (tile, head) run AT THE SAME TIME on neighbouring
+    // workgroups of one XCD.  With the public layout [q][head][level][point] a (query, head)'s seven levels share two or three
+    // 128-byte lines, which the ranges above fetch once per level (5 % L2 hit rate, 1.9 GB fetched per launch against 0.33 GB
+    // for rounds 2-4's kernel) and this order once -- and the launch is SLOWER for it (737 vs 667 us public, 619 vs 580 fused: every
+    // job pays the exact bound pass again, and the kernel is bound by VALU issue, not by those bytes).
     const int64_t total_jobs = (int64_t)units * L;
     const int nwg = (int)gridDim.x, rank = ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);      // (nwg is a multiple of 8)
-    const int64_t j_end = total_jobs * (rank + 1) / nwg;
+    const bool spread = (opts & 2) != 0;
+    const int64_t band = (total_jobs + 7) / 8;               // (spread) jobs of one XCD
+    const int64_t j_begin = spread ? ((int64_t)blockIdx.x >> 3) : total_jobs * rank / nwg;
+    const int64_t j_end = spread ? band : total_jobs * (rank + 1) / nwg;
+    const int64_t j_step = spread ? (nwg >> 3) : 0;
     [[maybe_unused]] int job_no = 0;
-    for (int64_t j = total_jobs * rank / nwg; j < j_end;) {
-        const int unit = (int)(j / L), l_first = (int)(j % L);
-        const int l_last = (int)((int64_t)L < l_first + (j_end - j) ? (int64_t)L : l_first + (j_end - j));    // (exclusive)
-        j += l_last - l_first;
+    for (int64_t j = j_begin; j < j_end;) {
+        const int64_t jj = spread ? ((int64_t)blockIdx.x & 7) * band + j : j;
+        if (spread) {
+            j += j_step;
+            if (jj >= total_jobs) continue;
+        }
+        const int unit = (int)(jj / L), l_first = (int)(jj % L);
+        const int l_last = spread ? l_first + 1
+                                  : (int)((int64_t)L < l_first + (j_end - j) ? (int64_t)L : l_first + (j_end - j));    // (exclusive)
+        if (!spread) j += l_last - l_first;
         const int head = unit % M, u2 = unit / M;             // the heads of a tile run back to back on one XCD
         const int tin = u2 % per_level, b = u2 / per_level;
         const int Y0 = (tin / tcols) * TH, X0 = (tin % tcols) * TW;
@@ -545,12 +567,10 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
 
                         if (s < 4 && c0 == 0) OTRACE(tr + 6 + 2 * s);
                         // ---- lanes as taps: the four (weight, record) entries of this lane's tap
-                        float x, y, a;
-                        tap_of(raw_, x, y, a);
+                        float x, y, fx, fy, wx1, wy1, a;
+                        tap_of(raw_, x, y, fx, fy, wx1, wy1, a);
                         const bool inw = in_window(x, y);
                         const bool hit = valid && !direct_only && inw;
-                        const float fx = floorf(x), fy = floorf(y);
-                        const float wx1 = x - fx, wy1 = y - fy;
                         {
                             const int tok = hit ? ((int)fy - oy) * WWP + ((int)fx - ox) : 0;
                             const float sw = hit ? a * scale : 0.f, ay1 = hit ? wy1 * sw : 0.f, ay0 = sw - ay1;
@@ -639,11 +659,12 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                         while (pend) {
                             const int src = __ffsll((long long)pend) - 1;
                             pend &= pend - 1;
-                            const float sx = __shfl(x, src, 64), sy = __shfl(y, src, 64), sa = __shfl(a, src, 64);
+                            const float sa = __shfl(a, src, 64);
+                            const float sfx = __shfl(fx, src, 64), sfy = __shfl(fy, src, 64), swx = __shfl(wx1, src, 64), swy = __shfl(wy1, src, 64);
                             const unsigned sg = (unsigned)__shfl((int)my_q, src, 64) * row_b;
                             const int cr = lane_o >> 4, j = lane_o & 15;
                             const float gk = *reinterpret_cast<const float *>(go_b + (sg + (unsigned)j * 4u));
-                            const Footprint<float> f = footprint(sy, sx, Hq, Wq);
+                            const Footprint<float> f = footprint_split(sfy, swy, sfx, swx, Hq, Wq);
                             const int yy = f.y0 + (cr >> 1), xx = f.x0 + (cr & 1);
                             const float wgt = ((cr >> 1) ? f.wy1 : f.wy0) * ((cr & 1) ? f.wx1 : f.wx0);
                             const bool ok = (unsigned)yy < (unsigned)Hq && (unsigned)xx < (unsigned)Wq;
@@ -816,6 +837,18 @@ int msda_backward_onepass_fused(hipStream_t st, const float *go, const float *va
                                                       ref, ref_bstride, raw_q, out_fwd, 0);
 }
 
+// job order of the grad_value-only launches: ranges (default: levels of a (tile, head) one after the other in a workgroup, guessed
+// scale) or spread (every level job on its own, the levels of a (tile, head) side by side on one XCD: see the kernel; measured
+// slower).  MVDETR_MSDA_BWD_ORDER = ranges | spread for A/B.
+static int onepass_order(int deflt)
+{
+    static const int forced = [] {
+        const char *e = getenv("MVDETR_MSDA_BWD_ORDER");
+        return !e ? -1 : !strcmp(e, "spread") ? 2 : !strcmp(e, "ranges") ? 0 : -1;
+    }();
+    return forced >= 0 ? forced : deflt;
+}
+
 // the grad_value half alone (DOTS = 0): the same jobs without the value window and the dot products
 // (grad_loc / grad_aw: written only when the level shapes turn out unequal on the device -- the lane-group fallback)
 int msda_backward_scatter(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -823,7 +856,7 @@ int msda_backward_scatter(hipStream_t st, const float *go, const float *value, c
                           float *grad_loc, float *grad_aw, bool standdown)
 {
     return launch_onepass<0, OnePassCfg<4, 16, 6, 0, 3>>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw,
-                                                         nullptr, 0, 0, nullptr, standdown ? 1 : 0);
+                                                         nullptr, 0, 0, nullptr, (standdown ? 1 : 0) | onepass_order(0));
 }
 
 int msda_backward_scatter_fused(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
@@ -831,7 +864,7 @@ int msda_backward_scatter_fused(hipStream_t st, const float *go, const float *va
                                 const float *stats, int B, int S, int M, int D, int L, float *grad_value)
 {
     return launch_onepass<1, OnePassCfg<4, 16, 6, 0, 3>>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr,
-                                                      ref, ref_bstride, raw_q, nullptr, 0);
+                                                         ref, ref_bstride, raw_q, nullptr, onepass_order(0));
 }
 
 }  // namespace mvdetr

@@ -241,5 +241,8 @@ def test_fused_training_pair_seeded_sweep(ops, i, L, H, W, B, noise):
     px = loc * torch.tensor([W, H], dtype=torch.float64) - 0.5
     smooth = ((px - px.round()).abs().amin(-1) > 1e-4).double()
     assert ((goff - goff_ref).abs() / (1.0 + goff_ref.abs()) * smooth[..., None]).max().item() < 2e-4, "grad of the raw offsets"
-    # (a logit's gradient is a * (d a - D) with d a a blend of <grad_out, value> dots of magnitude ~4: error against that scale)
-    assert ((glogit - glogit_ref).abs() / (4.0 + glogit_ref.abs())).max().item() < 2e-4, "grad of the raw logits"
+
+    # (round 4 measured this against 4 + |ref|: the kernels formed the pixel position as ONE fp32 number, 8e-6 px off at x ~ 143,
+    # which a blend of +-19 dots turns into 3e-4.  Round 5's kernels split the position -- common.h: fused_px -- and the bar is
+    # the other gradients' again)
+    assert ((glogit - glogit_ref).abs() / (1.0 + glogit_ref.abs())).max().item() < 2e-4, "grad of the raw logits"

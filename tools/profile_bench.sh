@@ -30,8 +30,8 @@ out = {}
 # bench.py key -> the kernels of one call (per-launch averages are summed: a call launches each of them once)
 groups = {"msda_fwd": ["msda_fwd_group"], "warp_fwd": ["warp_fwd_cl<"], "warp_fwd_nchw": ["warp_fwd<"],
           "warp_bwd": ["warp_bwd_scans", "warp_bwd_gather"],
-          "msda_bwd": ["msda_bwd_value_tok<16, 0>", "msda_bwd_sampling", "msda_locality_probe"],
-          "msda_train": ["msda_fwd_group2<%7, 2, 2>", "msda_bwd_value_tok<16, 1>", "msda_bwd_fused_sampling"]}
+          "msda_bwd": ["msda_bwd_onepass<0", "msda_bwd_sampling"],
+          "msda_train": ["msda_fwd_group2<%7, 2, 2>", "msda_bwd_onepass<1", "msda_bwd_fused_sampling"]}
 for key, kerns in groups.items():
     f = [avg("$O/pmc_fetch/p_results.db", "FETCH_SIZE", k) for k in kerns]
     w = [avg("$O/pmc_write/p_results.db", "WRITE_SIZE", k) for k in kerns]
