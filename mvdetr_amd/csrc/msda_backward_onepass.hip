@@ -37,6 +37,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef MVDETR_SCATTER_WGS
+#define MVDETR_SCATTER_WGS 3     // workgroups per CU of the grad_value-only instantiation (register budget 512 / this per lane)
+#endif
 #ifndef MVDETR_OP_STAGGER
 #define MVDETR_OP_STAGGER 16      // x 64 cycles between the waves of a workgroup at the start of pass 1 (0 = none)
 #endif
@@ -855,7 +858,7 @@ int msda_backward_scatter(hipStream_t st, const float *go, const float *value, c
                           const float *loc, const float *aw, int B, int S, int M, int D, int L, float *grad_value,
                           float *grad_loc, float *grad_aw, bool standdown)
 {
-    return launch_onepass<0, OnePassCfg<4, 16, 6, 0, 3>>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw,
+    return launch_onepass<0, OnePassCfg<4, 16, 6, 0, MVDETR_SCATTER_WGS>>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw,
                                                          nullptr, 0, 0, nullptr, (standdown ? 1 : 0) | onepass_order(0));
 }
 
@@ -863,7 +866,7 @@ int msda_backward_scatter_fused(hipStream_t st, const float *go, const float *va
                                 const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                 const float *stats, int B, int S, int M, int D, int L, float *grad_value)
 {
-    return launch_onepass<1, OnePassCfg<4, 16, 6, 0, 3>>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr,
+    return launch_onepass<1, OnePassCfg<4, 16, 6, 0, MVDETR_SCATTER_WGS>>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr,
                                                          ref, ref_bstride, raw_q, nullptr, onepass_order(0));
 }
 

@@ -74,8 +74,22 @@ def bench_tables(tag):
     if wp:
         extra.append(f"warp gradient with its geometry plan reused (`{wp['kernel']}` alone, the steady state of training without "
                      f"augmentation): {wp['avg_launch_us']} µs, {100 * wp['frac']:.1f} %")
+    wt = d.get("roofline_warp_bwd", {}).get("tagged")
+    if wt:
+        extra.append(f"the same through the ONE-call entry with a version tag of the matrices (`mvdetr_warp_perspective_backward_tagged_f32`, "
+                     f"ABI 12): {wt['avg_launch_us']} µs, {100 * wt['frac']:.1f} %")
     if extra:
         out += ["", "; ".join(extra) + "."]
+    sw = r.get("spread_sweep")
+    if sw and sw.get("avg_launch_us"):
+        out += ["", "`roofline.spread_sweep` — the same kernel in the model with the calibrated offset projections scaled to another spread "
+                    "(`roofline` itself is quoted at 1 px): "
+                + "; ".join(f"{k} {v} µs = {100 * sw['frac'][k]:.1f} %" for k, v in sw["avg_launch_us"].items()) + "."]
+    si = d.get("roofline_iid_offsets", {}).get("spread_sweep")
+    if si:
+        out += ["", "`roofline_iid_offsets.spread_sweep` — SURVEY 8d's microbenchmark input (offsets iid per tap) at other spreads: "
+                + "; ".join(f"{k} {v['avg_launch_us']} µs = {100 * v['frac']:.1f} %" for k, v in si.items())
+                + f"; 1px {d['roofline_iid_offsets']['avg_launch_us']} µs = {100 * d['roofline_iid_offsets']['frac']:.1f} %."]
     return out
 
 
@@ -125,7 +139,10 @@ def rocprof_table(tag, name, what):
 def generate(tag):
     lines = [BEGIN.format(tag=tag), ""]
     lines += bench_tables(tag)
-    lines += rocprof_table(tag, "kernel_stats.txt", "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gemm-tuning`")
+    lines += rocprof_table(tag, "kernel_stats_headline.txt", "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gemm-tuning "
+                           "--headline-only` (only the launches `roofline.avg_launch_us` averages: calibrated frames + hot-path passes)")
+    lines += rocprof_table(tag, "kernel_stats.txt", "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-gemm-tuning` (the forward "
+                           "kernel's row mixes six inputs here: calibrated, init weights, uncalibrated, the spread sweep, iid, training)")
     lines += microbench_tables(tag)
     lines += rocprof_table(tag, "microbench_kernel_stats.txt", "`python tools/microbench.py --iters 10` (realistic AND uniform inputs: "
                            "`min` is the realistic case)")

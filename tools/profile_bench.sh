@@ -12,11 +12,15 @@ mkdir -p $O
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-gemm-tuning $@"   # (tuning would fill the trace with candidate GEMMs)
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench.py $ARGS > $O/bench_under_trace.log 2>&1
+# the headline kernel alone: the same command restricted to the launches `roofline.avg_launch_us` averages (calibrated frames + hot-path
+# passes); the full run above launches msda_fwd_group2 on five other inputs too (init weights, uncalibrated, spread sweep, iid, training)
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_h -o t -- python $R/bench.py $ARGS --headline-only > $O/bench_under_trace_headline.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $O/pmc_fetch -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $O/pmc_write -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_sq -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_sq.log 2>&1
 cd $R
 python tools/rocpd_summary.py $O/trace/t_results.db > $O/${TAG}_kernel_stats.txt
+python tools/rocpd_summary.py $O/trace_h/t_results.db --filter mvdetr > $O/${TAG}_kernel_stats_headline.txt
 python tools/rocpd_summary.py $O/pmc_fetch/p_results.db --filter mvdetr > $O/${TAG}_pmc_fetch.txt
 python tools/rocpd_summary.py $O/pmc_write/p_results.db --filter mvdetr > $O/${TAG}_pmc_write.txt
 python tools/rocpd_summary.py $O/pmc_sq/p_results.db --filter mvdetr > $O/${TAG}_pmc_sq.txt
@@ -49,5 +53,5 @@ out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over:
 json.dump(out, open("$O/${TAG}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
-rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_sq
+rm -rf $O/trace $O/trace_h $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O
