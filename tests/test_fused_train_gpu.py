@@ -167,17 +167,19 @@ def test_module_trains_through_the_fused_pair(ops):
         assert params[k].grad.abs().max().item() > 0
 
 
-def test_fused_training_pair_at_wildtrack_size(ops):
-    """Full Wildtrack shape (75,600 queries x 8 heads x 7 levels x 4 points): every element of grad_value and of the raw
-    gradient against the fp64 C oracle chained through the module arithmetic."""
+@pytest.mark.parametrize("name,L,H,W,B", [("wildtrack", 7, 60, 180, 1), ("multiviewx_batch4", 6, 80, 125, 4)])
+def test_fused_training_pair_at_wildtrack_size(ops, name, L, H, W, B):
+    """Full Wildtrack shape (75,600 queries x 8 heads x 7 levels x 4 points) and BASELINE configs[3]'s encoder shape (MultiviewX,
+    6 cameras, 4 frames per step: 240,000 queries): every element of grad_value and of the raw gradient against the fp64 C oracle
+    chained through the module arithmetic."""
     MSDA = ops
-    L, H, W, M, D = 7, 60, 180, 8, 16
-    value, shapes, lsi, ref_ql, off, logit = _raw_inputs(L, H, W, M, D, 1, seed=0, noise_px=1.0)
+    M, D = 8, 16
+    value, shapes, lsi, ref_ql, off, logit = _raw_inputs(L, H, W, M, D, B, seed=0, noise_px=1.0)
     raw, rows = _to_raw(MSDA, off, logit, M, L, D)
     ref_lm = ref_ql.transpose(0, 1).contiguous()[None]
     dv, ds, dl, dr, draw = value.cuda(), shapes.cuda(), lsi.cuda(), ref_lm.cuda(), raw.cuda()
     out, stats = MSDA.ms_deform_attn_forward_fused_train(dv, ds, dl, dr, draw)
-    go = torch.randn(1, value.shape[1], M * D, generator=torch.Generator().manual_seed(9))
+    go = torch.randn(B, value.shape[1], M * D, generator=torch.Generator().manual_seed(9))
     gv, graw = MSDA.ms_deform_attn_backward_fused(go.cuda(), dv, ds, dl, dr, draw, stats, out)
     gv_ref, goff_ref, glogit_ref, loc, aw = _reference_grads(value, shapes, lsi, ref_ql, off, logit, go)
     inv = torch.empty_like(rows)
