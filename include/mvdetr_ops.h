@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 12   /* 12: + mvdetr_warp_perspective_backward_tagged_* */
+#define MVDETR_OPS_ABI_VERSION 13   /* 12: + mvdetr_warp_perspective_backward_tagged_*; 13: + mvdetr_msda_set_backward_deterministic */
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -289,6 +289,18 @@ int mvdetr_warp_release_scratch(void);
  * identical up to fp32 summation order; this is a tuning/testing knob.  Returns the previous value.
  * Initial value comes from MVDETR_MSDA_FWD_IMPL = auto | gather | tile. */
 int mvdetr_msda_set_forward_impl(int impl);
+
+/* Deterministic backward (opt-in; ABI 13).  The reference's col2im adds grad_value with atomicAdd
+ * (ms_deform_im2col_cuda.cuh:125-152) and is not reproducible run to run; neither are this library's default backward
+ * kernels (fp32 atomics when LDS windows are flushed).  With on != 0, mvdetr_msda_backward_f32 and
+ * mvdetr_msda_backward_fused_f32 sum grad_value in 64-bit fixed point with one binary point per call -- 38 bits below
+ * max|grad_out| x max(1, max|attn_weight|) -- so the result is bit-identical run to run (grad_sampling_loc / grad_attn_weight have
+ * one writer per element in every mode).  Costs a stream-ordered scratch of 8 bytes per value element and three small launches.
+ * Only deformable-encoder calls are served (fp32, 16-channel heads, equal level shapes, num_query == spatial_size,
+ * spatial_size * num_levels * num_point < 2^24); every other call returns hipErrorNotSupported (801) while the mode is on, and
+ * unequal level shapes (device data) fill grad_value with NaN.  Returns the previous state; the initial state comes from
+ * MVDETR_MSDA_BWD_DETERMINISTIC=1. */
+int mvdetr_msda_set_backward_deterministic(int on);
 
 /* dst[n][c][r] = src[n][r][c]: layout change between NCHW (rows = channels, cols = h*w) and the channel-last layout the
  * fast warp kernels read, and back.  Tiled through LDS, both sides move in 256-byte runs. */

@@ -23,7 +23,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 namespace mvdetr {
+
+// deterministic backward requested (mvdetr_msda_set_backward_deterministic; MVDETR_MSDA_BWD_DETERMINISTIC=1 sets the initial state)
+static std::atomic<int> &backward_deterministic()
+{
+    static std::atomic<int> on{[] { const char *e = getenv("MVDETR_MSDA_BWD_DETERMINISTIC"); return e && *e && strcmp(e, "0") ? 1 : 0; }()};
+    return on;
+}
 
 template <typename T, int VEC, int G, bool VALUE_GRAD = true>
 __global__ __launch_bounds__(256) void msda_bwd_lanes(
@@ -115,6 +124,7 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     constexpr int WIDE = 16 / (int)sizeof(T);
     const bool a16 = aligned(value, 16) && aligned(grad_col, 16);
+    if (sizeof(T) != 4 && backward_deterministic().load(std::memory_order_relaxed)) return (int)hipErrorNotSupported;
     if constexpr (sizeof(T) == 4) {
         // Encoder-shaped fp32 calls (the shapes the forward tile kernels take): grad_value through fixed-point LDS
         // windows (msda_backward_tile.hip), the other two gradients from LDS-staged value windows (msda_backward_sampling.hip).
@@ -131,6 +141,11 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
         }();
         const bool tile_shapes = tile_ok && msda_tile_supported(B, S, M, D, L, Lq, P, all16, 0, L);
         const bool op_ok = tile_shapes && msda_backward_onepass_supported(B, S, M, D, L, (int64_t)M * L * P * 2);
+        if (backward_deterministic().load(std::memory_order_relaxed)) {
+            // one kernel does it (msda_bwd_onepass<DET>); calls it does not take are refused, not served by a kernel that is not
+            if (!tile_shapes || !msda_backward_deterministic_supported(B, S, M, D, L, (int64_t)M * L * P * 2)) return (int)hipErrorNotSupported;
+            return msda_backward_onepass_det(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw);
+        }
         if (op_ok && impl == 1)
             return msda_backward_onepass(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, true);
         if (op_ok && impl == 0) {
@@ -204,6 +219,11 @@ int mvdetr_msda_backward_f32(void *stream, const float *grad_col, const float *v
                                          grad_sampling_loc, grad_attn_weight);
 }
 
+int mvdetr_msda_set_backward_deterministic(int on)
+{
+    return mvdetr::backward_deterministic().exchange(on ? 1 : 0);
+}
+
 int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const float *value,
                                    const int64_t *spatial_shapes, const int64_t *level_start_index,
                                    const float *reference_points, int64_t ref_batch_stride, const float *raw,
@@ -237,6 +257,13 @@ int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const
         return !e ? 0 : !strcmp(e, "onepass") ? 1 : !strcmp(e, "twopass") ? 2 : 0;
     }();
     const bool op_ok = msda_backward_onepass_supported(batch, spatial_size, num_heads, channels, num_levels, raw_query_stride);
+    if (backward_deterministic().load(std::memory_order_relaxed)) {
+        if (!msda_backward_deterministic_supported(batch, spatial_size, num_heads, channels, num_levels, raw_query_stride))
+            return (int)hipErrorNotSupported;
+        return msda_backward_onepass_fused_det(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                               reference_points, ref_batch_stride, stats, out, batch, spatial_size, num_heads,
+                                               channels, num_levels, grad_value, grad_raw);
+    }
     if (op_ok && impl == 1)
         return msda_backward_onepass_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
                                            reference_points, ref_batch_stride, stats, out, batch, spatial_size, num_heads,

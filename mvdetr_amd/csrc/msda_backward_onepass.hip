@@ -77,6 +77,18 @@ __device__ __forceinline__ float sum8(float v)
     return v;
 }
 
+// Deterministic mode (DET): grad_value is summed in 64-bit fixed point with ONE binary point for the whole call, 38 bits below
+// the product of the call's largest finite |grad_out| and largest finite |attention weight| (>= 1): integer adds commute, so the
+// result does not depend on the order in which workgroups flush.  hdr[0], hdr[1]: those two maxima as float bits (msda_det_absmax).
+__device__ __forceinline__ int det_binary_point(const unsigned *hdr)
+{
+    int eg = 0, ea = 0;
+    (void)frexpf(__uint_as_float(hdr[0]), &eg);
+    (void)frexpf(fmaxf(__uint_as_float(hdr[1]), 1.f), &ea);
+    return 38 - (eg + ea);
+}
+constexpr int DET_HDR_BYTES = 256;
+
 }  // namespace
 
 // DOTS_ = 0: the grad_value half alone (no value window, no dot products: the sampling gradients come from another kernel)
@@ -107,12 +119,15 @@ template <int TH_, int TW_, int R_, int DOTS_ = 1, int MAXWGS_ = 8> struct OnePa
 
 // NC: cameras (levels) per pass of the tap tables when the level count is a multiple of it (6, 7, 8: the pass is unrolled without
 // tests); 0 = any level count, passes of 8 with tests.
-template <int FUSED, typename Cfg, int NC>
+// DET: deterministic grad_value -- flushes and far taps add to det_acc (int64 per element, binary point from det_hdr) instead of
+// fp32 atomics on grad_value; msda_det_finish folds det_acc into grad_value afterwards.
+template <int FUSED, typename Cfg, int NC, bool DET = false>
 __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
     int L, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw,
-    const float *__restrict__ ref, int64_t ref_bstride, int raw_q, const float *__restrict__ out_fwd, int opts)
+    const float *__restrict__ ref, int64_t ref_bstride, int raw_q, const float *__restrict__ out_fwd, int opts,
+    long long *__restrict__ det_acc, const unsigned *__restrict__ det_hdr)
 {
     constexpr int D = 16, TH = Cfg::TH, TW = Cfg::TW, WH = Cfg::WH, WW = Cfg::WW, WWP = Cfg::WWP, LCH = Cfg::LCH, NPAIR = Cfg::NPAIR;
     constexpr int P = TILE_P, THREADS = Cfg::THREADS, NSLOT = Cfg::NSLOT, CAMS = Cfg::CAMS, NW = Cfg::NW, CELLS = Cfg::CELLS, IPT = Cfg::IPT;
@@ -142,8 +157,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (FUSED && !equal) {
-        // (the fused entry's callers promise equal level shapes: make the misuse loud)
+    if ((FUSED || DET) && !equal) {
+        // (the fused entry's callers promise equal level shapes, and the deterministic mode has no other kernel: make the misuse loud)
         for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < (int64_t)B * S * M * D; i += (int64_t)gridDim.x * THREADS)
             grad_value[i] = __builtin_nanf("");
         return;
@@ -158,6 +173,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
         return;
     }
 
+    [[maybe_unused]] int det_s = 0;                           // DET: binary point of det_acc
+    if constexpr (DET) det_s = __builtin_amdgcn_readfirstlane(det_binary_point(det_hdr));
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
     const int units = per_level * M * B;
@@ -336,6 +353,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
             // single huge weight can hide an overflow) and is repeated exactly if that exceeds the guess
             bool guess = l > l_first && Wprev > 0.f && Wprev < INFINITY && Gmax_u > 0.f && Gmax_u < INFINITY;
             float Wmax = 0.f, scale = 0.f, inv_scale = 0.f, mscale = 0.f;
+            [[maybe_unused]] int e_job = 0;                   // the job's fixed point: steps of 2^(e_job - 30)
             bool direct_only = false, no_scatter = false;
             bool repeat = false;                              // second run of the job: the far taps' scatter has been done
             for (;;) {
@@ -438,6 +456,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                     e = !(bound < INFINITY) ? 129 : e < -90 ? -90 : e;
                     scale = bound > 0.f && !direct_only ? ldexpf(1.f, 30 - e) : 0.f;
                     inv_scale = ldexpf(1.f, e - 30);
+                    e_job = e;
                 }
                 // ---- what pass 1 needs (lanes = taps, then lanes = (cell, corner, channel pair)).  Derived HERE, from an opaque copy of
                 //      the lane index, so that none of it is alive through the bound pass above
@@ -672,7 +691,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                             const float wgt = ((cr >> 1) ? f.wy1 : f.wy0) * ((cr & 1) ? f.wx1 : f.wx0);
                             const bool ok = (unsigned)yy < (unsigned)Hq && (unsigned)xx < (unsigned)Wq;
                             const int64_t vo = level_base + ch0 + ((int64_t)(ok ? yy : 0) * Wq + (ok ? xx : 0)) * row + j;
-                            if (ok && !repeat) atomicAdd(grad_value + vo, wgt * (gk * sa));
+                            if (ok && !repeat) {
+                                const float c = wgt * (gk * sa);
+                                if (DET && fabsf(c) < INFINITY)
+                                    atomicAdd(reinterpret_cast<unsigned long long *>(det_acc + vo), (unsigned long long)__double2ll_rn(ldexp((double)c, det_s)));
+                                else        // (DET: NaN / inf sums do not depend on the order either)
+                                    atomicAdd(grad_value + vo, c);
+                            }
                             if constexpr (DOTS) {
                                 const float vk = ok ? value[vo] : 0.f;
                                 float pr = gk * vk;
@@ -748,6 +773,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                 const int ch = tid_f % LCH, pair_f = ch >> 1;
                 const bool upper = ch & 1;
                 float *const gbase = grad_value + level_base + ch0 + ch;
+                // DET: job steps -> call steps, a shift by k bits (rounded to nearest when it is to the right)
+                [[maybe_unused]] long long *const dbase = DET ? det_acc + level_base + ch0 + ch : nullptr;
+                [[maybe_unused]] const int k_up = e_job - 30 + det_s, k_dn = -k_up > 40 ? 40 : -k_up < 1 ? 1 : -k_up;
                 for (int i0 = tid_f / LCH; i0 < NSLOT; i0 += 8 * (THREADS / LCH)) {
                     long long v[8];
 #pragma unroll
@@ -764,8 +792,15 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                             const int mine = upper ? hi : lo;
                             const int gy = oy + tok / WWP, gx = ox + tok % WWP;
                             // corners outside the level were accumulated like any other and are dropped here (zero padding)
-                            if (mine != 0 && (unsigned)gy < (unsigned)Hq && (unsigned)gx < (unsigned)Wq)
-                                atomicAdd(gbase + ((int64_t)gy * Wq + gx) * row, (float)mine * inv_scale);
+                            if (mine != 0 && (unsigned)gy < (unsigned)Hq && (unsigned)gx < (unsigned)Wq) {
+                                if constexpr (DET) {
+                                    const long long inc = k_up >= 0 ? (long long)mine << (k_up > 31 ? 31 : k_up)
+                                                                    : ((long long)mine + (1ll << (k_dn - 1))) >> k_dn;
+                                    if (inc) atomicAdd(reinterpret_cast<unsigned long long *>(dbase + ((int64_t)gy * Wq + gx) * row), (unsigned long long)inc);
+                                } else {
+                                    atomicAdd(gbase + ((int64_t)gy * Wq + gx) * row, (float)mine * inv_scale);
+                                }
+                            }
                         }
                     }
                 }
@@ -777,42 +812,44 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
     }
 }
 
-template <int FUSED, typename Cfg, int NC>
+template <int FUSED, typename Cfg, int NC, bool DET>
 static int launch_onepass_nc(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
                           const float *loc, const float *aw, int B, int S, int M, int L, float *grad_value, float *grad_loc,
-                          float *grad_aw, const float *ref, int64_t ref_bstride, int raw_q, const float *out_fwd, int opts)
+                          float *grad_aw, const float *ref, int64_t ref_bstride, int raw_q, const float *out_fwd, int opts,
+                          long long *det_acc, const unsigned *det_hdr)
 {
     constexpr int LDS = Cfg::LDS;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_onepass<FUSED, Cfg, NC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_onepass<FUSED, Cfg, NC, DET>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_onepass<FUSED, Cfg, NC>, Cfg::THREADS, LDS) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_onepass<FUSED, Cfg, NC, DET>, Cfg::THREADS, LDS) != hipSuccess || per_cu < 1)
             per_cu = Cfg::WGS;
         if (per_cu > Cfg::WGS) per_cu = Cfg::WGS;
         if (getenv("MVDETR_DEBUG_OCCUPANCY"))
-            fprintf(stderr, "msda_bwd_onepass<%d, %dx%d, %d>: %d workgroups per CU (LDS admits %d), %d B of LDS, %d threads\n", FUSED,
-                    Cfg::TH, Cfg::TW, NC, per_cu, Cfg::WGS, LDS, Cfg::THREADS);
+            fprintf(stderr, "msda_bwd_onepass<%d, %dx%d, %d, %d>: %d workgroups per CU (LDS admits %d), %d B of LDS, %d threads\n", FUSED,
+                    Cfg::TH, Cfg::TW, NC, (int)DET, per_cu, Cfg::WGS, LDS, Cfg::THREADS);
         return (cus * per_cu + 7) / 8 * 8;
     }();
-    hipLaunchKernelGGL((msda_bwd_onepass<FUSED, Cfg, NC>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, go, value, shapes, lsi, loc, aw,
-                       B, S, M, L, grad_value, grad_loc, grad_aw, ref, ref_bstride, raw_q, out_fwd, opts);
+    hipLaunchKernelGGL((msda_bwd_onepass<FUSED, Cfg, NC, DET>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, go, value, shapes, lsi, loc, aw,
+                       B, S, M, L, grad_value, grad_loc, grad_aw, ref, ref_bstride, raw_q, out_fwd, opts, det_acc, det_hdr);
     return (int)hipGetLastError();
 }
 
-template <int FUSED, typename Cfg>
+template <int FUSED, typename Cfg, bool DET = false>
 static int launch_onepass(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
                           const float *loc, const float *aw, int B, int S, int M, int L, float *grad_value, float *grad_loc,
-                          float *grad_aw, const float *ref, int64_t ref_bstride, int raw_q, const float *out_fwd, int opts)
+                          float *grad_aw, const float *ref, int64_t ref_bstride, int raw_q, const float *out_fwd, int opts,
+                          long long *det_acc = nullptr, const unsigned *det_hdr = nullptr)
 {
-#define NC_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, ref, ref_bstride, raw_q, out_fwd, opts
-    if (L % 7 == 0) return launch_onepass_nc<FUSED, Cfg, 7>(NC_ARGS);
-    if (L % 8 == 0) return launch_onepass_nc<FUSED, Cfg, 8>(NC_ARGS);
-    if (L % 6 == 0) return launch_onepass_nc<FUSED, Cfg, 6>(NC_ARGS);
-    return launch_onepass_nc<FUSED, Cfg, 0>(NC_ARGS);
+#define NC_ARGS st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, ref, ref_bstride, raw_q, out_fwd, opts, det_acc, det_hdr
+    if (L % 7 == 0) return launch_onepass_nc<FUSED, Cfg, 7, DET>(NC_ARGS);
+    if (L % 8 == 0) return launch_onepass_nc<FUSED, Cfg, 8, DET>(NC_ARGS);
+    if (L % 6 == 0) return launch_onepass_nc<FUSED, Cfg, 6, DET>(NC_ARGS);
+    return launch_onepass_nc<FUSED, Cfg, 0, DET>(NC_ARGS);
 #undef NC_ARGS
 }
 
@@ -838,6 +875,96 @@ int msda_backward_onepass_fused(hipStream_t st, const float *go, const float *va
 {
     return launch_onepass<1, OnePassCfg<4, 16, 6, 1>>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, grad_raw, nullptr,
                                                       ref, ref_bstride, raw_q, out_fwd, 0);
+}
+
+// ---- deterministic mode: the one-pass kernel with 64-bit fixed-point sums for grad_value ------------------------------------
+// (the reference's col2im adds with atomicAdd, cuh:125-152, and is not reproducible run to run; this is the opt-in that is.)
+// largest finite |a[i]| -> hdr[0], largest finite |b[i]| (or 1 without b) -> hdr[1], as float bits (which order like the floats)
+__global__ __launch_bounds__(256) void msda_det_absmax(const float *__restrict__ a, int64_t na4, const float *__restrict__ b,
+                                                       int64_t nb4, unsigned *__restrict__ hdr)
+{
+    auto scan = [&](const float *p, int64_t n4) {
+        unsigned m = 0u;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 v = reinterpret_cast<const float4 *>(p)[i];
+            const unsigned u[4] = {__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu,
+                                   __float_as_uint(v.z) & 0x7fffffffu, __float_as_uint(v.w) & 0x7fffffffu};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m = u[k] < 0x7f800000u && u[k] > m ? u[k] : m;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        return m;
+    };
+    const unsigned ma = scan(a, na4), mb = b ? scan(b, nb4) : __float_as_uint(1.f);
+    if ((threadIdx.x & 63) == 0) {
+        if (ma) atomicMax(hdr + 0, ma);
+        if (mb) atomicMax(hdr + 1, mb);
+    }
+}
+
+// grad_value += det_acc * 2^-binary point (one writer per element)
+__global__ __launch_bounds__(256) void msda_det_finish(const long long *__restrict__ acc, const unsigned *__restrict__ hdr,
+                                                       float *__restrict__ grad_value, int64_t n)
+{
+    const int s = det_binary_point(hdr);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long v = acc[i];
+        if (v) grad_value[i] += (float)ldexp((double)v, -s);
+    }
+}
+
+bool msda_backward_deterministic_supported(int B, int S, int M, int D, int L, int64_t q_floats)
+{
+    // (an element's sum stays below 2^38 x the taps that can land on it: 2^24 of them leave a factor two to int64)
+    return msda_backward_onepass_supported(B, S, M, D, L, q_floats) && (int64_t)S * L * TILE_P < ((int64_t)1 << 24);
+}
+
+template <int FUSED>
+static int onepass_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
+                       const float *loc, const float *aw, int B, int S, int M, int L, float *grad_value, float *grad_loc,
+                       float *grad_aw, const float *ref, int64_t ref_bstride, int raw_q, const float *out_fwd)
+{
+    const int64_t n = (int64_t)B * S * M * 16;
+    if (n == 0) return 0;
+    char *scratch = nullptr;
+    const size_t bytes = DET_HDR_BYTES + (size_t)n * sizeof(long long);
+    int rc = (int)hipMallocAsync(reinterpret_cast<void **>(&scratch), bytes, st);
+    if (rc) return rc;
+    unsigned *hdr = reinterpret_cast<unsigned *>(scratch);
+    long long *acc = reinterpret_cast<long long *>(scratch + DET_HDR_BYTES);
+    rc = (int)hipMemsetAsync(scratch, 0, bytes, st);
+    if (!rc) {
+        // (public contract: aw are the attention weights; fused: softmax weights, at most 1)
+        hipLaunchKernelGGL(msda_det_absmax, dim3(2048), dim3(256), 0, st, go, n / 4, FUSED ? nullptr : aw,
+                           FUSED ? (int64_t)0 : (int64_t)B * S * M * L * TILE_P / 4, hdr);
+        rc = (int)hipGetLastError();
+    }
+    if (!rc)
+        rc = launch_onepass<FUSED, OnePassCfg<4, 16, 6, 1>, true>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc,
+                                                                  grad_aw, ref, ref_bstride, raw_q, out_fwd, 0, acc, hdr);
+    if (!rc) {
+        hipLaunchKernelGGL(msda_det_finish, dim3(4096), dim3(256), 0, st, acc, hdr, grad_value, n);
+        rc = (int)hipGetLastError();
+    }
+    (void)hipFreeAsync(scratch, st);
+    return rc;
+}
+
+int msda_backward_onepass_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
+                              const float *loc, const float *aw, int B, int S, int M, int D, int L, float *grad_value,
+                              float *grad_loc, float *grad_aw)
+{
+    return onepass_det<0>(st, go, value, shapes, lsi, loc, aw, B, S, M, L, grad_value, grad_loc, grad_aw, nullptr, 0, 0, nullptr);
+}
+
+int msda_backward_onepass_fused_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                    const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                    const float *stats, const float *out_fwd, int B, int S, int M, int D, int L,
+                                    float *grad_value, float *grad_raw)
+{
+    return onepass_det<1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, grad_raw, nullptr, ref, ref_bstride, raw_q,
+                          out_fwd);
 }
 
 // job order of the grad_value-only launches: ranges (default: levels of a (tile, head) one after the other in a workgroup, guessed

@@ -78,6 +78,16 @@ int msda_backward_onepass_fused(hipStream_t st, const float *go, const float *va
                                 const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                 const float *stats, const float *out_fwd, int B, int S, int M, int D, int L,
                                 float *grad_value, float *grad_raw);
+// the same kernel with grad_value summed in 64-bit fixed point (one binary point per call): bit-reproducible run to run.  Opt-in
+// (mvdetr_msda_set_backward_deterministic / MVDETR_MSDA_BWD_DETERMINISTIC=1); stream-ordered scratch of 8 bytes per value element
+bool msda_backward_deterministic_supported(int B, int S, int M, int D, int L, int64_t q_floats);
+int msda_backward_onepass_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
+                              const float *loc, const float *aw, int B, int S, int M, int D, int L, float *grad_value,
+                              float *grad_loc, float *grad_aw);
+int msda_backward_onepass_fused_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                    const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                    const float *stats, const float *out_fwd, int B, int S, int M, int D, int L,
+                                    float *grad_value, float *grad_raw);
 // the grad_value half of the same kernel alone (no value window, no dot products): what the two-kernel backward launches for
 // grad_value since round 5 (units of L level jobs, guessed fixed-point scale, in-kernel window shift and stand-down)
 int msda_backward_scatter(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,

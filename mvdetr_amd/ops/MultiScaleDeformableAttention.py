@@ -316,3 +316,10 @@ def set_forward_impl(name: str) -> str:
     prev = _lib.lib().mvdetr_msda_set_forward_impl(_IMPLS[name])
     return {v: k for k, v in _IMPLS.items()}[prev]
 
+
+
+def set_backward_deterministic(on: bool) -> bool:
+    """Opt into the bit-reproducible backward (``mvdetr_msda_set_backward_deterministic``, include/mvdetr_ops.h): grad_value is
+    summed in 64-bit fixed point instead of with fp32 atomics (the reference's atomicAdd, cuh:125-152, is not reproducible
+    either).  Deformable-encoder calls only; any other backward raises while the mode is on.  Returns the previous state."""
+    return bool(_lib.lib().mvdetr_msda_set_backward_deterministic(1 if on else 0))
