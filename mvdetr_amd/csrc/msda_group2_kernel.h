@@ -29,7 +29,8 @@
 #include "msda_group_kernel.h"
 
 #ifndef MVDETR_GROUP2_TAIL_FLAT
-#define MVDETR_GROUP2_TAIL_FLAT 1     // 0: round 4's far-tap tail (per (camera, level): reload the level's sampling data, then gather)
+#define MVDETR_GROUP2_TAIL_FLAT 1     // far taps per round of the tail (2 was measured: the 32 gathers in flight spill INTO the tap
+                                      // stream, 111 vs 99 us at the headline); 0: round 4's far-tap tail (per (camera, level): reload the level's sampling data, then gather)
 #endif
 
 namespace mvdetr {
@@ -464,55 +465,78 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_fwd_group2(
                 if constexpr (FUSED) s = st_lane[Lds::st_row(c) / 2];
                 // taps that left the window: straight from global memory (zero padding by test)
 #if MVDETR_GROUP2_TAIL_FLAT
-                // ONE list per (lane, camera) -- bit 4 l + p of `mc` = point p of level l -- walked with the NEXT missed tap's
-                // sampling data requested before the current one's sixteen value gathers: a round trip per missed tap of the
-                // wave's worst lane.  (Before: per (camera, level) with any miss in the wave, the level's sampling data and
-                // then the gathers, two dependent round trips each -- 2 x 49 per job once the offsets spread to 2 px.)
+                // ONE list per (lane, camera) -- bit 4 l + p of `mc` = point p of level l -- walked FU entries at a time, with the
+                // next entries' sampling data requested before the current ones' gathers: a round trip per FU missed taps of
+                // the wave's worst lane.
+                // (Before: per (camera, level) with any miss in the wave, the level's sampling data and then the gathers, two
+                // dependent round trips each -- 2 x 49 per job once the offsets spread to 2 px.)
                 unsigned mc = 0u;
 #pragma unroll
                 for (int l = 0; l < L; ++l) mc |= ((ms_lane[l * NCL] >> (c * P)) & 15u) << (4 * l);
                 if (mc) {
-                    float2 nxy = make_float2(0.f, 0.f), nrf = nxy;
-                    float nlg = 0.f;
-                    int nl = 0;
-                    auto request = [&]() {                    // the list's first entry: sampling data on its way
-                        const int t_ = __ffs((int)mc) - 1, l_ = t_ >> 2, pp_ = t_ & 3;
-                        mc &= mc - 1;
-                        nl = l_;
-                        nxy = *reinterpret_cast<const float2 *>(lp + l_ * lay.l_l + pp_ * 2);
-                        nlg = wp[l_ * lay.l_w + pp_];
-                        if constexpr (FUSED) nrf = *reinterpret_cast<const float2 *>(rp + l_ * lay.r_l + (FUSED == 2 ? 0 : pp_ * 2));
+                    constexpr int FU = MVDETR_GROUP2_TAIL_FLAT;           // entries per round
+                    float2 nxy[FU], nrf[FU];
+                    float nlg[FU];
+                    int nl[FU];
+                    bool nok[FU];
+                    auto request = [&]() {                    // the list's first FU entries: sampling data on its way
+#pragma unroll
+                        for (int u = 0; u < FU; ++u) {
+                            nok[u] = mc != 0u;
+                            const int t_ = nok[u] ? __ffs((int)mc) - 1 : 0, l_ = t_ >> 2, pp_ = t_ & 3;
+                            mc &= mc - 1u;                    // (0 stays 0)
+                            nl[u] = l_;
+                            nxy[u] = *reinterpret_cast<const float2 *>(lp + l_ * lay.l_l + pp_ * 2);
+                            nlg[u] = wp[l_ * lay.l_w + pp_];
+                            nrf[u] = make_float2(0.f, 0.f);
+                            if constexpr (FUSED) nrf[u] = *reinterpret_cast<const float2 *>(rp + l_ * lay.r_l + (FUSED == 2 ? 0 : pp_ * 2));
+                        }
                     };
                     request();
                     for (;;) {
-                        float lx = nxy.x, ly = nxy.y, a = nlg;
-                        const float2 rf = nrf;
-                        const int l = nl;
+                        const float *r0[FU], *r1[FU];
+                        float wgt[FU][4];
+                        bool v00[FU], v01[FU], v10[FU], v11[FU];
+#pragma unroll
+                        for (int u = 0; u < FU; ++u) {
+                            float lx = nxy[u].x, ly = nxy[u].y, a = nlg[u];
+                            if constexpr (FUSED) {
+                                lx = nrf[u].x + lx * (1.f / fW);
+                                ly = nrf[u].y + ly * (1.f / fH);
+                                a = __expf(a - s.x);
+                            }
+                            float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
+                            const bool ok = nok[u] && y > -1.f && x > -1.f && y < fH && x < fW;        // (false for NaN)
+                            x = ok ? x : 0.f;
+                            y = ok ? y : 0.f;
+                            a = ok ? a : 0.f;
+                            const Footprint<float> f = footprint(y, x, Hq, Wq);
+                            r0[u] = vbatch + lsi[nl[u]] * row + lane_off + ((int64_t)f.y0 * Wq + f.x0) * row;
+                            r1[u] = r0[u] + (int64_t)Wq * row;
+                            wgt[u][0] = f.wy0 * f.wx0 * a; wgt[u][1] = f.wy0 * f.wx1 * a;
+                            wgt[u][2] = f.wy1 * f.wx0 * a; wgt[u][3] = f.wy1 * f.wx1 * a;
+                            v00[u] = ok && f.vy0 && f.vx0; v01[u] = ok && f.vy0 && f.vx1;
+                            v10[u] = ok && f.vy1 && f.vx0; v11[u] = ok && f.vy1 && f.vx1;
+                        }
                         const bool more = mc != 0u;
                         if (more) request();
-                        if constexpr (FUSED) {
-                            lx = rf.x + lx * (1.f / fW);
-                            ly = rf.y + ly * (1.f / fH);
-                            a = __expf(a - s.x);
-                        }
-                        const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
-                        if (y > -1.f && x > -1.f && y < fH && x < fW) {
-                            const Footprint<float> f = footprint(y, x, Hq, Wq);
-                            const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * Wq + f.x0) * row;
-                            const float *r1 = r0 + (int64_t)Wq * row;
-                            const float w00 = f.wy0 * f.wx0 * a, w01 = f.wy0 * f.wx1 * a;
-                            const float w10 = f.wy1 * f.wx0 * a, w11 = f.wy1 * f.wx1 * a;
 #pragma unroll
-                            for (int k = 0; k < NV; ++k) {
-                                const int ko = (k ^ rot) << 2;
-                                const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch);
-                                const float4 c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
-                                const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch);
-                                const float4 c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
-                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w00, c00);
-                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w01, c01);
-                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w10, c10);
-                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], w11, c11);
+                        for (int k = 0; k < NV; ++k) {
+                            const int ko = (k ^ rot) << 2;
+                            float4 c00[FU], c01[FU], c10[FU], c11[FU];
+#pragma unroll
+                            for (int u = 0; u < FU; ++u) {
+                                c00[u] = load4_or_zero(r0[u] + ko, v00[u], vbatch);
+                                c01[u] = load4_or_zero(r0[u] + row + ko, v01[u], vbatch);
+                                c10[u] = load4_or_zero(r1[u] + ko, v10[u], vbatch);
+                                c11[u] = load4_or_zero(r1[u] + row + ko, v11[u], vbatch);
+                            }
+#pragma unroll
+                            for (int u = 0; u < FU; ++u) {
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], wgt[u][0], c00[u]);
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], wgt[u][1], c01[u]);
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], wgt[u][2], c10[u]);
+                                gfma4(acc[c][2 * k], acc[c][2 * k + 1], wgt[u][3], c11[u]);
                             }
                         }
                         if (!more) break;
