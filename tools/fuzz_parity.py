@@ -62,6 +62,21 @@ def one_case(rnd, i):
             err = err * smooth[..., None]
         if err.max().item() >= 2e-4:
             bad.append((name, err.max().item(), ""))
+    # the deterministic mode (ABI 13; deformable-encoder calls of 16-channel heads): bit-identical over two runs, same bars
+    if D == 16:
+        MSDA.set_backward_deterministic(True)
+        try:
+            det = [[x.clone() for x in MSDA.ms_deform_attn_backward(*d, go.cuda(), 64)] for _ in range(2)]
+        finally:
+            MSDA.set_backward_deterministic(False)
+        if not all(torch.equal(a, b) for a, b in zip(*det)):
+            bad.append(("deterministic backward differs between two runs", 0.0, ""))
+        for a, b, name, scale in zip(det[0], ref, ("det grad_value", "det grad_loc", "det grad_aw"), (1.0, float(max(W, H)), 4.0)):
+            err = (a.cpu().double() - b).abs() / (scale + b.abs())
+            if name == "det grad_loc":
+                err = err * smooth[..., None]
+            if err.max().item() >= 2e-4:
+                bad.append((name, err.max().item(), ""))
     if MSDA.fused_supported(d[0], L, value.shape[1], 4):
         ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
         r3 = torch.stack([xs / W, ys / H], -1).reshape(1, H * W, 1, 2).repeat(B, L, L, 1)

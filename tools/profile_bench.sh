@@ -17,6 +17,10 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_h -o t -- python $R/bench.py $ARGS --headline-only > $O/bench_under_trace_headline.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum -d $O/pmc_fetch -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum -d $O/pmc_write -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_write.log 2>&1
+# the headline kernel's memory-side bytes from the launches `roofline` averages alone (the full run's msda_fwd_group2 rows mix in the
+# spread sweep and the iid input, whose far taps fetch more)
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch_h -o p -- python $R/bench.py $ARGS --headline-only > $O/bench_under_pmc_fetch_h.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write_h -o p -- python $R/bench.py $ARGS --headline-only > $O/bench_under_pmc_write_h.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/pmc_sq -o p -- python $R/bench.py $ARGS > $O/bench_under_pmc_sq.log 2>&1
 cd $R
 python tools/rocpd_summary.py $O/trace/t_results.db > $O/${TAG}_kernel_stats.txt
@@ -37,8 +41,9 @@ groups = {"msda_fwd": ["msda_fwd_group"], "warp_fwd": ["warp_fwd_cl<"], "warp_fw
           "msda_bwd": ["msda_bwd_onepass<0", "msda_bwd_sampling"],
           "msda_train": ["msda_fwd_group2<%7, 2, 2>", "msda_bwd_onepass<1", "msda_bwd_fused_sampling"]}
 for key, kerns in groups.items():
-    f = [avg("$O/pmc_fetch/p_results.db", "FETCH_SIZE", k) for k in kerns]
-    w = [avg("$O/pmc_write/p_results.db", "WRITE_SIZE", k) for k in kerns]
+    h = "_h" if key == "msda_fwd" else ""          # the headline kernel: the --headline-only passes
+    f = [avg("$O/pmc_fetch" + h + "/p_results.db", "FETCH_SIZE", k) for k in kerns]
+    w = [avg("$O/pmc_write" + h + "/p_results.db", "WRITE_SIZE", k) for k in kerns]
     f = [x for x in f if x is not None]
     w = [x for x in w if x is not None]
     if f and w:
@@ -46,12 +51,13 @@ for key, kerns in groups.items():
         out[key + "_write_size_kb"] = sum(w)
         out[key + "_bytes_per_launch"] = int((2 * sum(f) + sum(w)) * 1024)
         out[key + "_kernels"] = kerns
-out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over: python bench.py $ARGS; "
+out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over: python bench.py $ARGS (msda_fwd: the same with "
+               "--headline-only, i.e. only the launches roofline.avg_launch_us averages); "
                "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane "
                "reads (MI355X_MICROARCH.md, HBM section; re-checked here on a device copy of known size), WRITE_SIZE is exact. "
                "Infinity-Cache hits are included, so this is an upper bound on HBM bytes.")
 json.dump(out, open("$O/${TAG}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
-rm -rf $O/trace $O/trace_h $O/pmc_fetch $O/pmc_write $O/pmc_sq
+rm -rf $O/trace $O/trace_h $O/pmc_fetch $O/pmc_write $O/pmc_fetch_h $O/pmc_write_h $O/pmc_sq
 ls -la $O
