@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 13   /* 12: + mvdetr_warp_perspective_backward_tagged_*; 13: + mvdetr_msda_set_backward_deterministic */
+#define MVDETR_OPS_ABI_VERSION 13   /* 12: + mvdetr_warp_perspective_backward_tagged_*; 13: + mvdetr_msda_set_backward_deterministic; the fused training pair takes every encoder shape */
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -146,8 +146,12 @@ int mvdetr_msda_backward_f64(void *stream, const double *grad_col, const double 
  *         raw_query_stride floats between queries
  *   reference_points [batch or 1, L, Lq, 2]  ONE point per (query, level), level-major (MVDeTr's map; ref_batch_stride 0 when
  *         shared by the batch)
- * Shapes: queries = tokens (Lq = spatial_size), 6 or 7 levels OF EQUAL SHAPE (the caller's promise: on other shapes the
- * outputs are NaN), 4 points, 16-channel heads; mvdetr_msda_fused_train_supported says whether a call qualifies (1 / 0).
+ * Shapes: queries = tokens (Lq = spatial_size), up to 16 levels OF EQUAL SHAPE (the caller's promise: on other shapes the
+ * outputs are NaN), 4 points, 16- or 32-channel heads (an even number of 16-channel heads); mvdetr_msda_fused_train_supported
+ * says whether a call qualifies (1 / 0).  ABI 10 - 12 took 6 / 7 levels of 16-channel heads only (MVDeTr's own shapes: their
+ * kernels are msda_fwd_group2, msda_bwd_onepass and msda_bwd_fused_sampling); since ABI 13 every other encoder shape runs the
+ * inference forward of that shape + a statistics pass, and the one-pass backward (16 channels) or msda_bwd_value_tok + the
+ * level-groups sampling kernel (32 channels; not in the deterministic mode).
  * forward: out [batch, Lq, M*D] as mvdetr_msda_forward_fused_f32, plus stats [batch, Lq, M, 2] = (maximum logit,
  *          1 / sum of exp(logit - maximum)) of every (query, head), which the backward needs to rebuild the weights.
  * backward: grad_value [batch, S, M, D] (ACCUMULATED: zero it first) and grad_raw [batch, Lq, raw_query_stride] (the

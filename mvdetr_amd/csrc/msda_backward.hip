@@ -238,8 +238,7 @@ int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const
     if (!grad_output || !value || !spatial_shapes || !level_start_index || !reference_points || !raw || !stats || !out ||
         !grad_value || !grad_raw)
         return (int)hipErrorInvalidValue;
-    if (!mvdetr_msda_fused_train_supported(batch, spatial_size, num_heads, channels, num_levels, spatial_size, num_point) ||
-        channels != 16)
+    if (!mvdetr_msda_fused_train_supported(batch, spatial_size, num_heads, channels, num_levels, spatial_size, num_point))
         return (int)hipErrorNotSupported;
     if (raw_query_stride < num_heads * num_levels * num_point * 3 || raw_query_stride % 4) return (int)hipErrorInvalidValue;
     // the kernels address one batch element's raw tensor (and its gradient) with 32-bit offsets of the CALLER's query stride,
@@ -257,7 +256,23 @@ int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const
         return !e ? 0 : !strcmp(e, "onepass") ? 1 : !strcmp(e, "twopass") ? 2 : 0;
     }();
     const bool op_ok = msda_backward_onepass_supported(batch, spatial_size, num_heads, channels, num_levels, raw_query_stride);
-    if (backward_deterministic().load(std::memory_order_relaxed)) {
+    const bool det = backward_deterministic().load(std::memory_order_relaxed) != 0;
+    if (!det && !(channels == 16 && (num_levels == 6 || num_levels == 7))) {
+        // every other encoder shape (ABI 13): 16-channel heads -> the one-pass kernel (any level count); 32-channel heads ->
+        // msda_bwd_value_tok<32, fused> + the level-groups sampling kernel on the raw tensor
+        if (channels == 16 && op_ok)
+            return msda_backward_onepass_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                               reference_points, ref_batch_stride, stats, out, batch, spatial_size, num_heads,
+                                               channels, num_levels, grad_value, grad_raw);
+        int rc = msda_backward_value_tile_fused(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                                reference_points, ref_batch_stride, stats, batch, spatial_size, num_heads, channels,
+                                                num_levels, grad_value);
+        if (rc) return rc;
+        return msda_backward_fused_sampling_groups(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,
+                                                   reference_points, ref_batch_stride, stats, out, batch, spatial_size, num_heads,
+                                                   channels, num_levels, grad_raw);
+    }
+    if (det) {
         if (!msda_backward_deterministic_supported(batch, spatial_size, num_heads, channels, num_levels, raw_query_stride))
             return (int)hipErrorNotSupported;
         return msda_backward_onepass_fused_det(st, grad_output, value, spatial_shapes, level_start_index, raw, raw_query_stride,

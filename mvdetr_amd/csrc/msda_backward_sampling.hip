@@ -54,11 +54,9 @@ __device__ __forceinline__ float neighbour(float v)
 // d = <g, corner> for the four corners of the tap at pixel position (x, y) of a level, corners read from
 // global memory with zero padding; NV float4 chunks per lane, chunk k of `g` holds channels 4*(k^rot)..+3
 template <int NV>
-__device__ __forceinline__ void corners_from_memory(const float *__restrict__ vlevel, int64_t row, int H, int W, float x,
-                                                    float y, int rot, const float4 *g, f2 &d00, f2 &d01, f2 &d10,
-                                                    f2 &d11)
+__device__ __forceinline__ void corners_of_footprint(const float *__restrict__ vlevel, int64_t row, int W, const Footprint<float> &f,
+                                                     int rot, const float4 *g, f2 &d00, f2 &d01, f2 &d10, f2 &d11)
 {
-    const Footprint<float> f = footprint(y, x, H, W);
     const float *r0 = vlevel + ((int64_t)f.y0 * W + f.x0) * row, *r1 = r0 + (int64_t)W * row;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -68,6 +66,13 @@ __device__ __forceinline__ void corners_from_memory(const float *__restrict__ vl
         if (f.vy1 && f.vx0) d10 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + ko), d10);
         if (f.vy1 && f.vx1) d11 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + row + ko), d11);
     }
+}
+template <int NV>
+__device__ __forceinline__ void corners_from_memory(const float *__restrict__ vlevel, int64_t row, int H, int W, float x,
+                                                    float y, int rot, const float4 *g, f2 &d00, f2 &d01, f2 &d10,
+                                                    f2 &d11)
+{
+    corners_of_footprint<NV>(vlevel, row, W, footprint(y, x, H, W), rot, g, d00, d01, d10, d11);
 }
 
 // the same for a lane holding TWO chunks: chunk k of `g` is channels 4*((first + k)^rot)..+3
@@ -261,28 +266,37 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
 // every window is still staged once per (tile, head).  A lane's sampling data / gradients of a level group are contiguous
 // runs of LG x 32 / LG x 16 bytes.  (At Wildtrack size -- D = 16, L = 7 -- groups of 3 are no faster than all 7 resident:
 // 764 vs 747 us for the whole backward with one workgroup per CU, 827 us with two at 128 VGPRs, which spill.)
-template <int D, int LG, int WPE = 2>
+// FUSED = 1: the fused TRAINING backward's half of the same job (mvdetr_msda_backward_fused_f32 for calls the 6 / 7-camera
+// kernel msda_bwd_fused_sampling does not take: 32-channel heads, other level counts): `loc` is the module's raw tensor
+// [B, Lq, L, M / hps, (hps x P x 2 offsets in pixels | hps x P logits)] with `raw_q` floats per query, `aw` the forward's softmax
+// statistics [B, Lq, M, 2] (maximum, reciprocal sum), `ref` one reference point per (level, query) [.., L, Lq, 2], `out_fwd` the
+// forward's output; `grad_loc` is the gradient of the raw tensor -- offsets a (gx, gy), logits a (da - <grad_out, out>) -- and
+// `grad_aw` is unused.  The grad_value kernel of those calls never stands a tile down, so neither does this one.
+template <int D, int LG, int WPE = 2, int FUSED = 0>
 __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
-    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw, const int *__restrict__ local_hits)
+    int L, float *__restrict__ grad_loc, float *__restrict__ grad_aw, const int *__restrict__ local_hits,
+    const float *__restrict__ ref, int64_t ref_bstride, int raw_q, const float *__restrict__ out_fwd)
 {
     extern __shared__ __attribute__((aligned(16))) float vwin[];      // [LG][RS_NTOK][D]
     constexpr int TH = RS_TH, TW = RS_TW, WH = RS_WH, WW = RS_WW, NTOK = RS_NTOK, P = TILE_P;
     constexpr int HALF = D / 2, NV = HALF / 4, CH = D / 4, POS = 64 / CH, CAMS = RS_THREADS / 64;
+    constexpr int HPS = 32 / D, CHUNK = HPS * TILE_P * 3;     // (FUSED) heads per 128-byte slice; floats of a (query, level, slice) run
     static_assert(NTOK % POS == 0, "a DMA instruction covers POS window positions");
     const int tid = threadIdx.x;
     const int64_t row = (int64_t)M * D;
 
     bool equal = true;
     for (int l = 1; l < L; ++l) equal = equal && shapes[2 * l] == shapes[0] && shapes[2 * l + 1] == shapes[1];
-    if (local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
-    if (!equal) return;          // msda_bwd_value_win has done all three gradients for such calls
+    if (!FUSED && local_hits && *local_hits * MSDA_PROBE_NEAR_DIV < MSDA_PROBE_SAMPLES) equal = false;      // far-flung taps: same stand-down
+    if (!equal) return;          // the grad_value kernel has done all three gradients for such calls (FUSED: it has made the misuse loud)
 
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
     const int tcols = (Wq + TW - 1) / TW, per_level = ((Hq + TH - 1) / TH) * tcols;
     const int jobs = per_level * M * B, jobs8 = (jobs + 7) / 8;
     const float fW = (float)Wq, fH = (float)Hq;
+    [[maybe_unused]] const float iw = 1.f / fW, ih = 1.f / fH;
 
     // lane = (camera of the pass, cell, half of the head's channels): a wave is one camera's 32 cells
     const int sub = tid & 1, qi = (tid >> 1) & (TH * TW - 1), qly = qi / TW, qlx = qi % TW;
@@ -308,11 +322,23 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
             const int sY0 = Y0 / MSDA_SAMPLE_TH * MSDA_SAMPLE_TH, sX0 = X0 / MSDA_SAMPLE_TW * MSDA_SAMPLE_TW;
             const int s_qy = sY0 + lane / MSDA_SAMPLE_TW, s_qx = sX0 + lane % MSDA_SAMPLE_TW;
             const bool have = s_qy < Hq && s_qx < Wq;
-            const float *lp = loc + ((((int64_t)b * S + lsi[0] + (have ? (int64_t)s_qy * Wq + s_qx : 0)) * M + head) * L) * P * 2;
-            const float4 a0 = *reinterpret_cast<const float4 *>(lp), b0 = *reinterpret_cast<const float4 *>(lp + 4);
+            const int64_t s_q = (int64_t)b * S + lsi[0] + (have ? (int64_t)s_qy * Wq + s_qx : 0);
+            float4 a0, b0;
+            if constexpr (FUSED) {
+                const float *rp = loc + s_q * raw_q + (head / HPS) * CHUNK + (head % HPS) * P * 2;       // (level 0)
+                const float2 r = *reinterpret_cast<const float2 *>(ref + b * ref_bstride + (s_q - (int64_t)b * S) * 2);
+                a0 = *reinterpret_cast<const float4 *>(rp);
+                b0 = *reinterpret_cast<const float4 *>(rp + 4);
+                a0 = make_float4(__fmaf_rn(a0.x, iw, r.x), __fmaf_rn(a0.y, ih, r.y), __fmaf_rn(a0.z, iw, r.x), __fmaf_rn(a0.w, ih, r.y));
+                b0 = make_float4(__fmaf_rn(b0.x, iw, r.x), __fmaf_rn(b0.y, ih, r.y), __fmaf_rn(b0.z, iw, r.x), __fmaf_rn(b0.w, ih, r.y));
+            } else {
+                const float *lp = loc + ((s_q * M + head) * L) * P * 2;
+                a0 = *reinterpret_cast<const float4 *>(lp);
+                b0 = *reinterpret_cast<const float4 *>(lp + 4);
+            }
             bool far;
             msda_job_sample(a0, b0, have, s_qx, s_qy, fW, fH, shx, shy, far);
-            if (far) continue;
+            if (!FUSED && far) continue;
         }
         const int oy = Y0 + TH / 2 - WH / 2 + shy, ox = X0 + TW / 2 - WW / 2 + shx;
         const float cx = (float)ox + 0.5f * (WW - 1), cy = (float)oy + 0.5f * (WH - 1);
@@ -343,12 +369,35 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
 #pragma unroll
                 for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const float4 *>(go + q * row + head * D + sub * HALF + ((k ^ rot) << 2));
                 float4 la[LG], lb[LG], wa[LG];
+                [[maybe_unused]] float2 rf[LG];               // (FUSED) reference point of (level, query)
+                [[maybe_unused]] float2 st = make_float2(0.f, 1.f);
+                [[maybe_unused]] float dq = 0.f;              // (FUSED) <grad_out, out> of the (query, head)
+                // (FUSED) the raw tensor's run of (query, level, slice): this head's offsets, then its logits
+                [[maybe_unused]] const int64_t r0_ = q * raw_q + (head / HPS) * CHUNK + (head % HPS) * P * 2;
+                [[maybe_unused]] const int64_t w0_ = q * raw_q + (head / HPS) * CHUNK + HPS * P * 2 + (head % HPS) * P;
+                [[maybe_unused]] const int l_stride = (M / HPS) * CHUNK;
 #pragma unroll
                 for (int j = 0; j < LG; ++j) {
                     const int jj = j < ng ? j : ng - 1;
-                    la[j] = *reinterpret_cast<const float4 *>(loc + (e0 + jj * P) * 2);
-                    lb[j] = *reinterpret_cast<const float4 *>(loc + (e0 + jj * P) * 2 + 4);
-                    wa[j] = *reinterpret_cast<const float4 *>(aw + e0 + jj * P);
+                    if constexpr (FUSED) {
+                        la[j] = *reinterpret_cast<const float4 *>(loc + r0_ + (g0 + jj) * l_stride);
+                        lb[j] = *reinterpret_cast<const float4 *>(loc + r0_ + (g0 + jj) * l_stride + 4);
+                        wa[j] = *reinterpret_cast<const float4 *>(loc + w0_ + (g0 + jj) * l_stride);
+                        rf[j] = *reinterpret_cast<const float2 *>(ref + b * ref_bstride + ((int64_t)(g0 + jj) * S + (q - (int64_t)b * S)) * 2);
+                    } else {
+                        la[j] = *reinterpret_cast<const float4 *>(loc + (e0 + jj * P) * 2);
+                        lb[j] = *reinterpret_cast<const float4 *>(loc + (e0 + jj * P) * 2 + 4);
+                        wa[j] = *reinterpret_cast<const float4 *>(aw + e0 + jj * P);
+                    }
+                }
+                if constexpr (FUSED) {
+                    st = *reinterpret_cast<const float2 *>(aw + (q * M + head) * 2);
+                    f2 dq2 = {0.f, 0.f};
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+                        dq2 = dot4(g[k], *reinterpret_cast<const float4 *>(out_fwd + q * row + head * D + sub * HALF + ((k ^ rot) << 2)), dq2);
+                    dq = hsum(dq2);
+                    dq += neighbour(dq);
                 }
                 if (c0 == 0) __syncthreads();                 // the group's windows have landed
                 float4 r_aw[LG], r_l0[LG], r_l1[LG];
@@ -356,16 +405,29 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
                 for (int j = 0; j < LG; ++j) {
                     if (j >= ng) continue;                    // (uniform)
                     const float *wl = vwin + j * NTOK * D;
-                    const float xs[4] = {la[j].x * fW - 0.5f, la[j].z * fW - 0.5f, lb[j].x * fW - 0.5f, lb[j].z * fW - 0.5f};
-                    const float ys[4] = {la[j].y * fH - 0.5f, la[j].w * fH - 0.5f, lb[j].y * fH - 0.5f, lb[j].w * fH - 0.5f};
+                    // (FUSED: offsets in pixels; the position is formed in two parts, common.h fused_px)
+                    const float lxs[4] = {la[j].x, la[j].z, lb[j].x, lb[j].z}, lys[4] = {la[j].y, la[j].w, lb[j].y, lb[j].w};
                     const float as[4] = {wa[j].x, wa[j].y, wa[j].z, wa[j].w};
                     float ga[4], gx[4], gy[4];
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
-                        const float x = xs[p], y = ys[p];
+                        float x, y, fx, fy, wx1, wy1, a;
+                        if constexpr (FUSED) {
+                            fused_px(rf[j].x, lxs[p], fW, x, fx, wx1);
+                            fused_px(rf[j].y, lys[p], fH, y, fy, wy1);
+                            a = __expf(as[p] - st.x) * st.y;
+                        } else {
+                            x = lxs[p] * fW - 0.5f;
+                            y = lys[p] * fH - 0.5f;
+                            fx = floorf(x);
+                            fy = floorf(y);
+                            wx1 = x - fx;
+                            wy1 = y - fy;
+                            a = as[p];
+                        }
                         f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
                         if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
-                            const int ix = (int)floorf(x) - ox, iy = (int)floorf(y) - oy;
+                            const int ix = (int)fx - ox, iy = (int)fy - oy;
                             const float *p00 = wl + (iy * WW + ix) * D + sub * HALF;
 #pragma unroll
                             for (int k = 0; k < NV; ++k) {
@@ -376,18 +438,27 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
                                 q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D + D), q11);
                             }
                         } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {   // (lanes without a cell carry cell 0's taps)
-                            corners_from_memory<NV>(vbatch + lsi[g0 + j] * row + sub * HALF, row, Hq, Wq, x, y, rot, g, q00, q01, q10, q11);
+                            corners_of_footprint<NV>(vbatch + lsi[g0 + j] * row + sub * HALF, row, Wq, footprint_split(fy, wy1, fx, wx1, Hq, Wq),
+                                                     rot, g, q00, q01, q10, q11);
                         }
                         float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
                         d00 += neighbour(d00);                // the other half of the head sits in the neighbouring lane
                         d01 += neighbour(d01);
                         d10 += neighbour(d10);
                         d11 += neighbour(d11);
-                        const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                        const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
                         const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
-                        ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
-                        gx[p] = in_image ? fW * as[p] * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-                        gy[p] = in_image ? fH * as[p] * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                        const float da = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
+                        if constexpr (FUSED) {
+                            // (a tap outside the image still has a logit: its weight takes part in the softmax)
+                            ga[p] = a * (da - dq);
+                            gx[p] = in_image ? a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+                            gy[p] = in_image ? a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                        } else {
+                            ga[p] = da;
+                            gx[p] = in_image ? fW * a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+                            gy[p] = in_image ? fH * a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                        }
                         __builtin_amdgcn_sched_barrier(0);    // one tap's LDS reads in flight at a time
                     }
                     r_aw[j] = make_float4(ga[0], ga[1], ga[2], ga[3]);
@@ -398,9 +469,15 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
 #pragma unroll
                     for (int j = 0; j < LG; ++j) {
                         if (j >= ng) continue;
-                        *reinterpret_cast<float4 *>(grad_aw + e0 + j * P) = r_aw[j];
-                        *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2) = r_l0[j];
-                        *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2 + 4) = r_l1[j];
+                        if constexpr (FUSED) {
+                            *reinterpret_cast<float4 *>(grad_loc + w0_ + (g0 + j) * l_stride) = r_aw[j];
+                            *reinterpret_cast<float4 *>(grad_loc + r0_ + (g0 + j) * l_stride) = r_l0[j];
+                            *reinterpret_cast<float4 *>(grad_loc + r0_ + (g0 + j) * l_stride + 4) = r_l1[j];
+                        } else {
+                            *reinterpret_cast<float4 *>(grad_aw + e0 + j * P) = r_aw[j];
+                            *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2) = r_l0[j];
+                            *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2 + 4) = r_l1[j];
+                        }
                     }
                 }
             }
@@ -408,14 +485,15 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
     }
 }
 
-template <int D, int LG, int WPE = 2>
+template <int D, int LG, int WPE = 2, int FUSED = 0>
 static int launch_sampling_groups(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                   const int64_t *lsi, const float *loc, const float *aw, int B, int S, int M, int L,
-                                  float *grad_loc, float *grad_aw, const int *local_hits)
+                                  float *grad_loc, float *grad_aw, const int *local_hits, const float *ref = nullptr,
+                                  int64_t ref_bstride = 0, int raw_q = 0, const float *out_fwd = nullptr)
 {
     constexpr int LDS = LG * RS_NTOK * D * 4;
     static int blocks = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_groups<D, LG, WPE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_groups<D, LG, WPE, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -423,8 +501,8 @@ static int launch_sampling_groups(hipStream_t st, const float *go, const float *
             cus = 256;
         return (cus * (WPE / 2) + 7) / 8 * 8;                 // WPE / 2 workgroups of 8 waves per CU
     }();
-    hipLaunchKernelGGL((msda_bwd_sampling_groups<D, LG, WPE>), dim3((unsigned)blocks), dim3(RS_THREADS), LDS, st, go, value, shapes,
-                       lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits);
+    hipLaunchKernelGGL((msda_bwd_sampling_groups<D, LG, WPE, FUSED>), dim3((unsigned)blocks), dim3(RS_THREADS), LDS, st, go, value, shapes,
+                       lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits, ref, ref_bstride, raw_q, out_fwd);
     return (int)hipGetLastError();
 }
 
@@ -457,6 +535,18 @@ int msda_backward_sampling_tile(hipStream_t st, const float *go, const float *va
     if (D == 32) return launch_sampling_groups<32, 3>(SAMPLING_ARGS);
     if (D == 16) return launch_sampling_groups<16, 7>(SAMPLING_ARGS);
     return (int)hipErrorInvalidValue;
+}
+
+// the fused TRAINING backward's sampling half for calls msda_backward_fused_sampling (6 / 7 levels of 16-channel heads) does not
+// take: the level-groups kernel on the raw tensor (see its header)
+int msda_backward_fused_sampling_groups(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                        const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                        const float *stats, const float *out_fwd, int B, int S, int M, int D, int L, float *grad_raw)
+{
+    if ((int64_t)S * M * D * 4 >= 0x7fffffffLL) return (int)hipErrorNotSupported;
+    if (D == 32) return launch_sampling_groups<32, 3, 2, 1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_raw, nullptr, nullptr, ref, ref_bstride, raw_q, out_fwd);
+    if (D == 16) return launch_sampling_groups<16, 7, 2, 1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_raw, nullptr, nullptr, ref, ref_bstride, raw_q, out_fwd);
+    return (int)hipErrorNotSupported;
 }
 
 }  // namespace mvdetr

@@ -569,6 +569,7 @@ int msda_backward_value_tok_fused(hipStream_t st, const float *go, const float *
                                   const float *stats, int B, int S, int M, int D, int L, float *grad_value)
 {
     if (D == 16) return launch_value_tok<16, 1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr, nullptr, ref, ref_bstride, raw_q);
+    if (D == 32) return launch_value_tok<32, 1>(st, go, value, shapes, lsi, raw, stats, B, S, M, L, grad_value, nullptr, nullptr, nullptr, ref, ref_bstride, raw_q);
     return (int)hipErrorNotSupported;
 }
 

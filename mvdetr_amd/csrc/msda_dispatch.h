@@ -69,6 +69,11 @@ int msda_backward_value_tile_fused(hipStream_t st, const float *go, const float 
 int msda_backward_fused_sampling(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                  const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                  const float *stats, const float *out_fwd, int B, int S, int M, int D, int L, float *grad_raw);
+// the sampling half of the fused training backward for every other encoder shape (32-channel heads, other level counts): the
+// level-groups kernel of msda_backward_sampling.hip on the raw tensor
+int msda_backward_fused_sampling_groups(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
+                                        const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
+                                        const float *stats, const float *out_fwd, int B, int S, int M, int D, int L, float *grad_raw);
 // the whole encoder-shaped fp32 backward in ONE kernel (msda_backward_onepass.hip): 16-channel heads; no probe, no scratch
 bool msda_backward_onepass_supported(int B, int S, int M, int D, int L, int64_t q_floats);
 int msda_backward_onepass(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,

@@ -262,11 +262,13 @@ int mvdetr_msda_fused_train_supported(int batch, int spatial_size, int num_heads
                                       int num_point)
 {
     using namespace mvdetr;
-    // what msda_fwd_group2 and the fused backward take: 6 or 7 levels (of equal shape: the caller's promise), 16- or
-    // 32-channel heads, 4 points, queries = tokens, 32-bit offsets inside one batch element
+    // every deformable-encoder shape the LDS-tiled kernels take: up to 16 levels (of equal shape: the caller's promise), 16- or
+    // 32-channel heads, 4 points, queries = tokens.  6 / 7 levels of 16-channel heads (MVDeTr's own) run msda_fwd_group2 +
+    // msda_bwd_onepass<grad_value only> + msda_bwd_fused_sampling; other level counts the one-pass backward (16 channels) or
+    // msda_bwd_value_tok + the level-groups sampling kernel (32 channels) behind the inference forward + a statistics pass.
     if (!msda_tile_supported(batch, spatial_size, num_heads, channels, num_levels, num_query, num_point, true, 0, num_levels)) return 0;
-    if (!(num_levels == 6 || num_levels == 7) || channels != 16 || !msda_group_supported(channels, num_levels)) return 0;
-    // (the whole raw tensor, all batch elements: msda_group_fits)
+    // (the whole raw tensor, all batch elements, in 32-bit float offsets: msda_group_fits; one element's in 2^29 for the backward)
+    if ((int64_t)spatial_size * num_heads * num_levels * num_point * 3 >= ((int64_t)1 << 29)) return 0;
     return (int64_t)batch * spatial_size * num_heads * num_levels * num_point * 3 < ((int64_t)1 << 30) ? 1 : 0;
 }
 

@@ -51,6 +51,37 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WAVES_PER_SIMD) void msda_fwd_ti
     msda_fwd_tile_body<Cfg, FUSED>(win, value, shapes, lsi, loc, aw, ref, ref_bstride, lay, qr, B, S, M, L, out);
 }
 
+// (maximum, 1 / sum exp) per (query, head): what msda_fwd_group2 leaves in `stats` from its online softmax, for the fused
+// training calls that kernel does not take.  The backward recomputes a = __expf(logit - max) * (1 / sum) with the same intrinsic.
+__global__ __launch_bounds__(256) void msda_softmax_stats_kernel(const float *__restrict__ logits, SamplingLayout lay,
+                                                                 int64_t queries, int M, int L, float *__restrict__ stats)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < queries * M; i += (int64_t)gridDim.x * 256) {
+        const int head = (int)(i % M);
+        const float *wp = logits + (i / M) * lay.q_w + lay.head_w(head);
+        float m = -INFINITY;
+        for (int l = 0; l < L; ++l) {
+            const float4 v = *reinterpret_cast<const float4 *>(wp + l * lay.l_w);
+            m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const float4 v = *reinterpret_cast<const float4 *>(wp + l * lay.l_w);
+            s += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m));
+        }
+        *reinterpret_cast<float2 *>(stats + i * 2) = make_float2(m, 1.f / s);
+    }
+}
+
+int msda_softmax_stats(hipStream_t st, const float *logits, SamplingLayout lay, int64_t queries, int M, int L, float *stats)
+{
+    const int64_t n = queries * M;
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(msda_softmax_stats_kernel, dim3(blocks), dim3(256), 0, st, logits, lay, queries, M, L, stats);
+    return (int)hipGetLastError();
+}
+
 bool msda_tile_supported(int B, int S, int M, int D, int L, int Lq, int P, bool aligned16, int ql0, int ql1)
 {
     if (!aligned16 || P != TILE_P || L > TILE_MAX_LEVELS || B < 1) return false;
@@ -157,14 +188,21 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     // A query-sharded call (a rank's own cameras as queries, mvdetr_amd/dist.py) has too few query levels per
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
-    if (all_levels && msda_group_supported(D, L) && msda_group_fits(B, S, M * D, lay))
-        return msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
-                                  M, D, L, out, nullptr, false, stats);
-    if (stats) return (int)hipErrorNotSupported;            // the training entry exists where msda_fwd_group2 takes the call
-    return shared_ref ? dispatch_tile<2>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
-                                         QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out)
-                      : dispatch_tile<1>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
-                                         QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out);
+    const bool grouped = all_levels && msda_group_supported(D, L) && msda_group_fits(B, S, M * D, lay);
+    // the training entry's statistics: msda_fwd_group2 (6 / 7 levels) writes them itself; every other route runs as it does for
+    // inference and a small pass over the logits follows
+    const bool own_stats = grouped && L <= 7;
+    int rc;
+    if (grouped)
+        rc = msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,
+                                M, D, L, out, nullptr, false, own_stats ? stats : nullptr);
+    else
+        rc = shared_ref ? dispatch_tile<2>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
+                                           QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out)
+                        : dispatch_tile<1>(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, lay,
+                                           QueryLevels{ql0, ql1, Lq}, B, S, M, D, L, out);
+    if (!rc && stats && !own_stats) rc = msda_softmax_stats(st, logits, lay, (int64_t)B * Lq, M, L, stats);
+    return rc;
 }
 
 }  // namespace mvdetr

@@ -68,6 +68,10 @@ struct QueryLevels {
     int begin, end, Lq;
 };
 
+// the fused training forward's statistics -- (maximum, 1 / sum exp) of a (query, head)'s L x P logits -- for calls whose forward
+// kernel does not write them itself (msda_fwd_group2 does): msda_forward_tile.hip
+int msda_softmax_stats(hipStream_t st, const float *logits, SamplingLayout lay, int64_t queries, int M, int L, float *stats);
+
 // camera-grouped fused forward (msda_forward_group.hip)
 bool msda_group_supported(int D, int L);
 // its per-lane addresses are 32-bit float offsets from per-batch, per-camera bases: one batch element's reference points and

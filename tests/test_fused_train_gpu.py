@@ -67,10 +67,15 @@ def _reference_grads(value, shapes, lsi, ref_ql, off, logit, go):
     return gv, g_off, g_logit, loc, aw
 
 
-@pytest.mark.parametrize("L,H,W,B,noise", [(7, 13, 21, 1, 1.0), (6, 12, 34, 2, 2.5), (7, 6, 16, 1, 0.0)])
-def test_fused_training_pair_vs_oracle(ops, L, H, W, B, noise):
+@pytest.mark.parametrize("L,H,W,B,noise,M,D", [
+    (7, 13, 21, 1, 1.0, 8, 16), (6, 12, 34, 2, 2.5, 8, 16), (7, 6, 16, 1, 0.0, 8, 16),
+    # ABI 13: every encoder shape of the LDS-tiled kernels -- other level counts (16-channel heads: the one-pass backward; the
+    # forward is the inference kernel of that shape + a statistics pass) ...
+    (3, 12, 20, 1, 1.0, 8, 16), (5, 9, 17, 2, 1.0, 4, 16), (8, 10, 18, 1, 1.5, 8, 16), (12, 7, 19, 1, 1.0, 4, 16), (16, 6, 14, 1, 2.0, 2, 16),
+    # ... and 32-channel heads (msda_bwd_value_tok<32, fused> + the level-groups sampling kernel on the raw tensor)
+    (6, 12, 20, 1, 1.0, 4, 32), (7, 9, 21, 2, 2.0, 8, 32), (16, 6, 14, 1, 1.0, 2, 32), (3, 11, 13, 1, 0.0, 2, 32), (9, 5, 33, 1, 6.0, 1, 32)])
+def test_fused_training_pair_vs_oracle(ops, L, H, W, B, noise, M, D):
     MSDA = ops
-    M, D = 8, 16
     value, shapes, lsi, ref_ql, off, logit = _raw_inputs(L, H, W, M, D, B, seed=3, noise_px=noise)
     raw, rows = _to_raw(MSDA, off, logit, M, L, D)
     ref_lm = ref_ql.transpose(0, 1).contiguous()[None]                # [1, L, Lq, 2]
@@ -211,16 +216,24 @@ def _fused_sweep_cases(n=8, seed=77):
         H, W = rnd.randint(1, 30), rnd.randint(1, 70)
         B = rnd.choice([1, 1, 2])
         noise = rnd.choice([0.0, 1.0, 3.0, 8.0])                  # 8 px: most taps leave their windows (the far paths)
-        cases.append((i, L, H, W, B, noise))
+        cases.append((i, L, H, W, B, noise, 8, 16))
+    # the general routes (ABI 13): any level count, both head widths
+    for i in range(n, 2 * n):
+        L = rnd.choice([3, 4, 5, 8, 9, 12, 16, 6, 7])
+        D = rnd.choice([16, 32, 32])
+        M = rnd.choice([2, 4, 8]) if D == 16 else rnd.choice([1, 2, 4])
+        H, W = rnd.randint(1, 24), rnd.randint(1, 60)
+        while L * H * W * M * D * L > 60_000_000:                 # (the fp64 chain on the CPU)
+            H, W = max(1, H // 2), max(1, W * 2 // 3)
+        cases.append((i, L, H, W, rnd.choice([1, 1, 2]), rnd.choice([0.0, 1.0, 3.0, 8.0]), M, D))
     return cases
 
 
-@pytest.mark.parametrize("i,L,H,W,B,noise", _fused_sweep_cases())
-def test_fused_training_pair_seeded_sweep(ops, i, L, H, W, B, noise):
+@pytest.mark.parametrize("i,L,H,W,B,noise,M,D", _fused_sweep_cases())
+def test_fused_training_pair_seeded_sweep(ops, i, L, H, W, B, noise, M, D):
     """Random geometry (partial tiles, single rows / columns, two frames, offsets from 0 to 8 px) through the fused training pair
     against the fp64 chain; the regression form of tools/fuzz_parity.py's fused leg."""
     MSDA = ops
-    M, D = 8, 16
     value, shapes, lsi, ref_ql, off, logit = _raw_inputs(L, H, W, M, D, B, seed=200 + i, noise_px=noise)
     S = value.shape[1]
     if not MSDA.fused_train_supported(B, S, M, D, L, S, 4):

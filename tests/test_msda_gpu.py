@@ -527,6 +527,9 @@ def test_fused_module_forward_vs_oracle_and_unfused(ops, L, H, W, B, d_model):
 
 
 def test_fused_path_is_inference_only_and_training_still_matches(ops):
+    """Three levels: outside MVDeTr's 6 / 7, where the fused TRAINING pair stopped until ABI 13.  With the pair switched off a
+    call that needs gradients takes the reference's unfused arithmetic + MSDeformAttnFunction; with it on (the default) it takes
+    the pair's general route (inference forward + statistics pass, one-pass backward) -- same output, same gradients."""
     _, MSDA = ops
     L, H, W, M, P, d_model = 3, 10, 18, 8, 4, 128
     mod = _module_with_random_projections(d_model, L, M, P, seed=1).cuda().train()
@@ -535,10 +538,23 @@ def test_fused_path_is_inference_only_and_training_still_matches(ops):
     query = torch.randn(1, S, d_model, device="cuda", requires_grad=True)
     ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
     ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, P, 1)[None].cuda()
+    mod.fused_training = False
     out = mod(query, ref, query, shapes, level_start_index(shapes))
-    assert MSDA.last_forward_impl() == "tile"                      # grad mode: the differentiable path
+    assert MSDA.last_forward_impl() == "tile"                      # grad mode, pair off: the differentiable path
     out.square().mean().backward()
     assert query.grad is not None and mod.sampling_offsets.weight.grad.abs().sum() > 0
+    unfused = [query.grad.clone(), mod.sampling_offsets.weight.grad.clone(), mod.attention_weights.weight.grad.clone(),
+               mod.value_proj.weight.grad.clone()]
+    query.grad = None
+    mod.zero_grad()
+    mod.fused_training = True
+    out_f = mod(query, ref, query, shapes, level_start_index(shapes))
+    assert MSDA.last_forward_impl() == "tile_fused"                # grad mode, pair on: its general route
+    out_f.square().mean().backward()
+    assert (out_f - out).abs().max().item() < 2e-5
+    fused = [query.grad, mod.sampling_offsets.weight.grad, mod.attention_weights.weight.grad, mod.value_proj.weight.grad]
+    for a, b in zip(fused, unfused):
+        assert (a - b).abs().max().item() < 2e-4 * (1.0 + b.abs().max().item())
     with torch.no_grad():
         out2 = mod(query, ref, query, shapes, level_start_index(shapes))
     assert MSDA.last_forward_impl() == "tile_fused"

@@ -95,7 +95,7 @@ def one_case(rnd, i):
     # the fused TRAINING pair (6 / 7 equal levels of 16-channel heads): raw offsets / logits in, their gradient out, against the
     # C oracle's backward chained through loc = ref + off / (W, H) and the softmax by hand in fp64 (tests/test_fused_train_gpu.py)
     S = value.shape[1]
-    if D == 16 and MSDA.fused_train_supported(B, S, M, D, L, S, 4):
+    if MSDA.fused_train_supported(B, S, M, D, L, S, 4):
         ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
         cells = torch.stack([xs / W, ys / H], -1).reshape(-1, 2).repeat(L, 1)                       # [S, 2]
         wh = torch.tensor([W, H], dtype=torch.float64)
