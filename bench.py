@@ -280,6 +280,18 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
             else "msda_bwd_value_tok + msda_bwd_sampling_groups (+ locality probe, memset of grad_value)", us, mn, bbytes, launches,
             "MultiScaleDeformableAttention.ms_deform_attn_backward (public contract), SURVEY 8d's locality-realistic input: "
             "bias grid + N(0, 1 px) offsets, softmax(N(0,1)) weights")
+        if D_ == 16:
+            # the opt-in bit-reproducible mode (mvdetr_msda_set_backward_deterministic, ABI 13): one kernel, 64-bit fixed-point sums
+            MSDA.set_backward_deterministic(True)
+            try:
+                us_d, mn_d = time_launches(lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, gout, 64), max(4, launches // 2))
+            finally:
+                MSDA.set_backward_deterministic(False)
+            out["roofline_msda_bwd"]["deterministic"] = {
+                "kernel": "msda_det_absmax + msda_bwd_onepass<deterministic> + msda_det_finish (+ memsets of grad_value and the 64-bit accumulators)",
+                "avg_launch_us": round(us_d, 2), "min_launch_us": round(mn_d, 2),
+                "frac": round(bbytes / (us_d * 1e-6) / 1e9 / PEAK_HBM_GBS, 4),
+                "what": "the same call with mvdetr_msda_set_backward_deterministic(1): grad_value bit-identical run to run"}
         del value, loc, aw, gout
         # the fused TRAINING pair (what MSDeformAttn.forward runs when gradients are needed): forward from the raw offsets /
         # logits + softmax statistics, backward to grad_value and the gradient of the raw tensor.  Bytes: SURVEY 8d's counts
@@ -310,7 +322,10 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
             us_f, mn_f = time_launches(lambda: MSDA.ms_deform_attn_forward_fused_train(value, shapes, lsi, ref_lm, raw), launches)
             us_b, mn_b = time_launches(lambda: MSDA.ms_deform_attn_backward_fused(gout, value, shapes, lsi, ref_lm, raw, st_, o_), launches)
             out["roofline_train_step"] = roofline_entry(
-                "msda_fwd_group2 (+ statistics) ; msda_bwd_onepass<fused, grad_value only> + msda_bwd_fused_sampling (+ memset of grad_value)",
+                "msda_fwd_group2 (+ statistics) ; msda_bwd_onepass<fused, grad_value only> + msda_bwd_fused_sampling (+ memset of grad_value)"
+                if (D_ == 16 and N in (6, 7)) else
+                "inference forward of the shape + msda_softmax_stats ; msda_bwd_onepass<fused> (+ memset of grad_value)" if D_ == 16 else
+                "inference forward of the shape + msda_softmax_stats ; msda_bwd_value_tok<32, fused> + msda_bwd_sampling_groups<fused> (+ memset of grad_value)",
                 us_f + us_b, mn_f + mn_b, fbytes + bbytes, launches,
                 "mvdetr_msda_forward_fused_train_f32 + mvdetr_msda_backward_fused_f32 on the same realistic input in raw form",
                 {"forward_us": round(us_f, 2), "backward_us": round(us_b, 2),

@@ -78,6 +78,10 @@ def bench_tables(tag):
     if wt:
         extra.append(f"the same through the ONE-call entry with a version tag of the matrices (`mvdetr_warp_perspective_backward_tagged_f32`, "
                      f"ABI 12): {wt['avg_launch_us']} µs, {100 * wt['frac']:.1f} %")
+    bd = d.get("roofline_msda_bwd", {}).get("deterministic")
+    if bd:
+        extra.append(f"MSDA backward in the opt-in bit-reproducible mode (`mvdetr_msda_set_backward_deterministic`, ABI 13): "
+                     f"{bd['avg_launch_us']} µs, {100 * bd['frac']:.1f} %")
     if extra:
         out += ["", "; ".join(extra) + "."]
     sw = r.get("spread_sweep")
