@@ -108,6 +108,35 @@ __device__ __forceinline__ void load_pair(const T *p, bool v0, bool v1, T &a, T 
     b = v1 ? p[1] : T(0);
 }
 
+// a destination pixel's bilinear footprint in the source view: what the channel-last kernels and (round 5) warp_fwd share
+// per tile through LDS
+template <typename T> struct WarpTexel {
+    int o00;                     // element offset of corner (y0, x0) inside the view, in texels (not scaled by C)
+    T w00, w01, w10, w11;
+    int valid;                   // bit 0..3: corners 00, 01, 10, 11 inside the source
+};
+
+template <typename T>
+__device__ __forceinline__ WarpTexel<T> warp_texel(const T *__restrict__ Mn, int i, int j, int h, int w, bool live, int nearest)
+{
+    WarpTexel<T> t;
+    t.o00 = 0;
+    t.valid = 0;
+    t.w00 = t.w01 = t.w10 = t.w11 = T(0);
+    if (live) {
+        double x, y;
+        source_position(Mn, i, j, h, w, x, y);
+        const SrcCoord sc = make_coord(x, y, h, w, nearest);
+        t.o00 = sc.y0 * w + sc.x0;
+        t.w00 = T(sc.wy0 * sc.wx0);
+        t.w01 = T(sc.wy0 * sc.wx1);
+        t.w10 = T(sc.wy1 * sc.wx0);
+        t.w11 = T(sc.wy1 * sc.wx1);
+        t.valid = (sc.v00 ? 1 : 0) | (sc.v01 ? 2 : 0) | (sc.v10 ? 4 : 0) | (sc.v11 ? 8 : 0);
+    }
+    return t;
+}
+
 // Block id -> (view, 8x8 destination tile, channel group).  The world grid is not aligned with the image
 // axes (a ground-plane row is a slanted, perspective-foreshortened line in the camera image), so 64
 // consecutive pixels of one destination ROW gather from ~30 different source cache lines per load
@@ -146,6 +175,9 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
     int nearest, T *__restrict__ dst)
 {
     __shared__ float tile[NHWC && sizeof(T) == 4 ? WARP_PIX * (WARP_CH + 1) : 1];
+    // the tile's geometry once per block, by its first wave (round 5: every wave used to run the fp64 inverse, the two
+    // divisions and the footprint for its own copy of the 64 pixels -- ~300 instructions in front of 16 channels x 12)
+    __shared__ WarpTexel<T> tex[WARP_PIX];
     const int lane = threadIdx.x & (WARP_PIX - 1);
     const int sub = threadIdx.x / WARP_PIX;
     WarpBlock wb;
@@ -155,27 +187,21 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
     const int cbase = wb.group * WARP_CH;
     constexpr int CPT = WARP_CH / WARP_SUB;
     const bool live = i < H && j < W;
-    SrcCoord sc;
-    sc.any = false;
-    if (live) {
-        double x, y;
-        source_position(Mv + (int64_t)n * 9, i, j, h, w, x, y);
-        sc = make_coord(x, y, h, w, nearest);
-    }
-    const T w00 = T(sc.wy0 * sc.wx0), w01 = T(sc.wy0 * sc.wx1);
-    const T w10 = T(sc.wy1 * sc.wx0), w11 = T(sc.wy1 * sc.wx1);
+    if (sub == 0) tex[lane] = warp_texel(Mv + (int64_t)n * 9, i, j, h, w, live, nearest);
+    __syncthreads();
+    const WarpTexel<T> t = tex[lane];
+    const bool v00 = t.valid & 1, v01 = t.valid & 2, v10 = t.valid & 4, v11 = t.valid & 8;
     const int64_t plane = (int64_t)h * w;
-    const int64_t o00 = (int64_t)sc.y0 * w + sc.x0;
 #pragma unroll 4
     for (int k = 0; k < CPT; ++k) {
         const int c = cbase + sub * CPT + k;
         T val = T(0);
-        if (live && c < C && sc.any) {
-            const T *sp = src + ((int64_t)n * C + c) * plane + o00;
+        if (live && c < C && t.valid) {
+            const T *sp = src + ((int64_t)n * C + c) * plane + t.o00;
             T a, b, cc, d;
-            load_pair(sp, sc.v00, sc.v01, a, b);
-            load_pair(sp + w, sc.v10, sc.v11, cc, d);
-            val = w00 * a + w01 * b + w10 * cc + w11 * d;
+            load_pair(sp, v00, v01, a, b);
+            load_pair(sp + w, v10, v11, cc, d);
+            val = t.w00 * a + t.w01 * b + t.w10 * cc + t.w11 * d;
         }
         if constexpr (!NHWC) {
             if (live && c < C) dst[(((int64_t)n * C + c) * H + i) * W + j] = val;
@@ -195,6 +221,134 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_fwd(
             const int pi = wb.i0 + p / WARP_TW, pj = wb.j0 + p % WARP_TW;
             if (pi < H && pj < W && cbase + ch < C)
                 dst[(((int64_t)n * H + pi) * W + pj) * C + cbase + ch] = (T)tile[p * (WARP_CH + 1) + ch];
+        }
+    }
+}
+
+// ---- NCHW source -> NCHW destination through LDS source patches (fp32; round 5) -------------------------------------------
+// warp_fwd<NCHW> issues one 8-byte gather per (pixel, channel, corner row): 1.2 M wave-level gathers at Wildtrack size, each
+// touching 8 - 16 cache lines of which it uses a few bytes -- it runs at the rate of the texture-address / L1 pipeline (85 - 90 us,
+// 30 % of the HBM roofline; computing the tile's fp64 geometry once per block instead of once per wave changed nothing).  The
+// destination grid is denser than the source (360 x 120 from 160 x 90), so the pre-image of an 8 x 32 destination tile is a
+// compact patch of ~8 x 16 texels per channel.  Here a workgroup = (8 x 32 tile, chunk of up to 32 channels): the four waves find
+// the bounding box of their footprints, copy the patch rows of every channel of the chunk to LDS with LDS-DMA (16 bytes per lane,
+// x aligned down to 4 texels: whole 64-byte row pieces, every byte of a fetched line used), and every lane blends its pixel's four
+// corners from LDS -- four ds_read_b32, masked by the corner's validity (zero padding and mode='nearest' need no zero-filled
+// border and multiply no unloaded value) -- and stores 128-byte rows.  The chunk shrinks with the patch (LDS budget / patch size);
+// a tile whose patch would leave fewer than 4 channels per chunk (extreme magnification near the horizon) gathers from memory as
+// warp_fwd does, in the same launch.
+#ifndef MVDETR_WARP_PP_CH
+#define MVDETR_WARP_PP_CH 32
+#endif
+#ifndef MVDETR_WARP_PP_FLOATS
+#define MVDETR_WARP_PP_FLOATS 8192          // 32 KB of LDS: 5 workgroups per CU
+#endif
+constexpr int WARP_PP_TH = 8, WARP_PP_TW = 32, WARP_PP_CH = MVDETR_WARP_PP_CH, WARP_PP_FLOATS = MVDETR_WARP_PP_FLOATS;
+static_assert(WARP_PP_TH * WARP_PP_TW == 256, "one lane per tile pixel, four waves");
+
+__global__ __launch_bounds__(256) void warp_fwd_nchw_patch(
+    const float *__restrict__ src, const float *__restrict__ Mv, int N, int C, int h, int w, int H, int W,
+    int nearest, float *__restrict__ dst)
+{
+    extern __shared__ __attribute__((aligned(16))) float patch[];       // [channel of the chunk][patch row][PWp]
+    __shared__ int box[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = (W + WARP_PP_TW - 1) / WARP_PP_TW, ty = (H + WARP_PP_TH - 1) / WARP_PP_TH;
+    const int groups = (C + WARP_PP_CH - 1) / WARP_PP_CH;
+    int r = blockIdx.x;
+    const int group = r % groups;
+    r /= groups;
+    const int j0 = (r % tx) * WARP_PP_TW;
+    r /= tx;
+    const int i0 = (r % ty) * WARP_PP_TH, n = r / ty;
+    if (n >= N) return;
+    const int i = i0 + tid / WARP_PP_TW, j = j0 + tid % WARP_PP_TW;
+    const bool live = i < H && j < W;
+    double sx = 0.0, sy = 0.0;
+    if (live) source_position(Mv + (int64_t)n * 9, i, j, h, w, sx, sy);
+    SrcCoord sc = make_coord(sx, sy, h, w, nearest);
+    const bool use = live && sc.any;
+    const bool v00 = use && sc.v00, v01 = use && sc.v01, v10 = use && sc.v10, v11 = use && sc.v11;
+    const float w00 = (float)(sc.wy0 * sc.wx0), w01 = (float)(sc.wy0 * sc.wx1), w10 = (float)(sc.wy1 * sc.wx0), w11 = (float)(sc.wy1 * sc.wx1);
+
+    // bounding box of the VALID corners (inside the image by construction)
+    int xmin = 0x3fffffff, xmax = -0x3fffffff, ymin = 0x3fffffff, ymax = -0x3fffffff;
+    if (v00 || v10) { xmin = min(xmin, sc.x0); xmax = max(xmax, sc.x0); }
+    if (v01 || v11) { xmin = min(xmin, sc.x0 + 1); xmax = max(xmax, sc.x0 + 1); }
+    if (v00 || v01) { ymin = min(ymin, sc.y0); ymax = max(ymax, sc.y0); }
+    if (v10 || v11) { ymin = min(ymin, sc.y0 + 1); ymax = max(ymax, sc.y0 + 1); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = min(xmin, __shfl_xor(xmin, o, 64));
+        xmax = max(xmax, __shfl_xor(xmax, o, 64));
+        ymin = min(ymin, __shfl_xor(ymin, o, 64));
+        ymax = max(ymax, __shfl_xor(ymax, o, 64));
+    }
+    if (lane == 0) { box[wave][0] = xmin; box[wave][1] = xmax; box[wave][2] = ymin; box[wave][3] = ymax; }
+    __syncthreads();
+    xmin = min(min(box[0][0], box[1][0]), min(box[2][0], box[3][0]));
+    xmax = max(max(box[0][1], box[1][1]), max(box[2][1], box[3][1]));
+    ymin = min(min(box[0][2], box[1][2]), min(box[2][2], box[3][2]));
+    ymax = max(max(box[0][3], box[1][3]), max(box[2][3], box[3][3]));
+
+    const int c0 = group * WARP_PP_CH, cn = min(WARP_PP_CH, C - c0);
+    const int64_t plane = (int64_t)h * w, oplane = (int64_t)H * W;
+    float *const op = dst + ((int64_t)n * C + c0) * oplane + (int64_t)i * W + j;
+    if (xmax < xmin) {
+        // no pixel of the tile touches the source: zeros
+        if (live)
+            for (int c = 0; c < cn; ++c) op[c * oplane] = 0.f;
+        return;
+    }
+    const int xs = xmin & ~3, PWp = ((xmax + 1 - xs) + 3) & ~3, PH = ymax - ymin + 1, PE = PH * PWp, Q = PWp >> 2;
+    int chunk = WARP_PP_FLOATS / PE;
+    chunk = chunk > cn ? cn : chunk;
+    if (chunk < 4 && chunk < cn) {
+        // the patch does not fit: per-lane gathers for this tile (warp_fwd's arithmetic)
+        if (live) {
+            const int64_t o00 = (int64_t)sc.y0 * w + sc.x0;
+            for (int c = 0; c < cn; ++c) {
+                float val = 0.f;
+                if (use) {
+                    const float *sp = src + ((int64_t)n * C + c0 + c) * plane + o00;
+                    float a, b, cc, d;
+                    load_pair(sp, v00, v01, a, b);
+                    load_pair(sp + w, v10, v11, cc, d);
+                    val = w00 * a + w01 * b + w10 * cc + w11 * d;
+                }
+                op[c * oplane] = val;
+            }
+        }
+        return;
+    }
+    // this lane's corners inside a channel's patch (an invalid corner reads slot 0 and is masked)
+    const int ry = sc.y0 - ymin, rx = sc.x0 - xs;
+    const int r00 = v00 ? ry * PWp + rx : 0, r01 = v01 ? ry * PWp + rx + 1 : 0;
+    const int r10 = v10 ? (ry + 1) * PWp + rx : 0, r11 = v11 ? (ry + 1) * PWp + rx + 1 : 0;
+    // the view's channels c0.. through one buffer descriptor (the launcher checks that a view stays below 2^31 bytes)
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(src + ((int64_t)n * C + c0) * plane), 0, (int)((unsigned)cn * (unsigned)plane * 4u), 0x00020000);
+    for (int cb = 0; cb < cn; cb += chunk) {
+        const int cc_n = min(chunk, cn - cb), items = cc_n * PH * Q;      // 16-byte pieces of this chunk's patches
+        if (cb) __syncthreads();                                          // everyone is done reading the previous chunk
+        for (int base = wave * 64; base < items; base += 256) {
+            const int it = base + lane;
+            const int ch = it / (PH * Q), rem = it - ch * (PH * Q), row = rem / Q, q = rem - row * Q;
+            const unsigned vo = it < items ? (unsigned)(((cb + ch) * (int)plane + (ymin + row) * w + xs + 4 * q) * 4) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void *)(patch + base * 4), 16, (int)vo, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's copies have landed ...
+        __syncthreads();                                                  // ... and everyone's
+        if (live) {
+            const float *pc = patch;
+            float *o = op + (int64_t)cb * oplane;
+#pragma unroll 4
+            for (int c = 0; c < cc_n; ++c) {
+                const float a = v00 ? pc[r00] : 0.f, b = v01 ? pc[r01] : 0.f, cq = v10 ? pc[r10] : 0.f, d = v11 ? pc[r11] : 0.f;
+                *o = w00 * a + w01 * b + w10 * cq + w11 * d;
+                pc += PE;
+                o += oplane;
+            }
         }
     }
 }
@@ -241,33 +395,6 @@ __global__ __launch_bounds__(WARP_PIX *WARP_SUB) void warp_bwd(
 // contiguous C-vector: a lane takes 16 bytes of it, the C/4 (fp32) lanes of a pixel read whole 512-byte rows,
 // and a pixel's geometry is evaluated once (fp64) by one lane and shared through LDS instead of once per
 // channel group.
-template <typename T> struct WarpTexel {
-    int o00;                     // element offset of corner (y0, x0) inside the view, in texels (not scaled by C)
-    T w00, w01, w10, w11;
-    int valid;                   // bit 0..3: corners 00, 01, 10, 11 inside the source
-};
-
-template <typename T>
-__device__ __forceinline__ WarpTexel<T> warp_texel(const T *__restrict__ Mn, int i, int j, int h, int w, bool live, int nearest)
-{
-    WarpTexel<T> t;
-    t.o00 = 0;
-    t.valid = 0;
-    t.w00 = t.w01 = t.w10 = t.w11 = T(0);
-    if (live) {
-        double x, y;
-        source_position(Mn, i, j, h, w, x, y);
-        const SrcCoord sc = make_coord(x, y, h, w, nearest);
-        t.o00 = sc.y0 * w + sc.x0;
-        t.w00 = T(sc.wy0 * sc.wx0);
-        t.w01 = T(sc.wy0 * sc.wx1);
-        t.w10 = T(sc.wy1 * sc.wx0);
-        t.w11 = T(sc.wy1 * sc.wx1);
-        t.valid = (sc.v00 ? 1 : 0) | (sc.v01 ? 2 : 0) | (sc.v10 ? 4 : 0) | (sc.v11 ? 8 : 0);
-    }
-    return t;
-}
-
 constexpr int WARP_CL_THREADS = 256;
 
 template <typename T>
@@ -1160,6 +1287,20 @@ static int warp_entry(bool backward, void *stream, const T *a, const T *Mv, int 
     if (!backward) {
         // NCHW source: 8x8-tile gather kernel for both destination layouts (91 us / 28 % at Wildtrack size for
         // NCHW -> NCHW, the literal layouts of the kornia call; every replacement tried was slower)
+        if constexpr (sizeof(T) == 4) {
+            // fp32 NCHW -> NCHW (the literal kornia layouts): LDS source patches where whole 16-byte row pieces can be copied
+            // (rows of a multiple of 4 texels, aligned base, a view below 2 GiB); MVDETR_WARP_FWD_NCHW=gather keeps the gather kernel
+            static const bool patch_ok = [] { const char *e = getenv("MVDETR_WARP_FWD_NCHW"); return !(e && !strcmp(e, "gather")); }();
+            if (!nhwc && patch_ok && w % 4 == 0 && aligned(a, 16) && (int64_t)C * h * w * 4 < 0x7fffffffLL) {
+                const int64_t pb = (int64_t)N * ((H + WARP_PP_TH - 1) / WARP_PP_TH) * ((W + WARP_PP_TW - 1) / WARP_PP_TW) *
+                                   ((C + WARP_PP_CH - 1) / WARP_PP_CH);
+                if (pb <= 0x7fffffffLL) {
+                    hipLaunchKernelGGL(warp_fwd_nchw_patch, dim3((unsigned)pb), dim3(256), WARP_PP_FLOATS * 4, st, a, Mv, N, C, h, w, H, W, nearest, o);
+                    g_warp_last_kernel = "warp_fwd_nchw_patch";
+                    return (int)hipGetLastError();
+                }
+            }
+        }
         if (nhwc) hipLaunchKernelGGL((warp_fwd<T, true>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
         else hipLaunchKernelGGL((warp_fwd<T, false>), grid, block, 0, st, a, Mv, N, C, h, w, H, W, nearest, o);
         g_warp_last_kernel = nhwc ? "warp_fwd<NHWC>" : "warp_fwd<NCHW>";

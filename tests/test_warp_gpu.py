@@ -274,8 +274,10 @@ def test_kernel_name_per_layout_route(warp):
     src = torch.randn(7, 128, 90, 160, generator=torch.Generator().manual_seed(0)).cuda()
     src_cl = src.contiguous(memory_format=torch.channels_last)
     warp(src, M, (120, 360))
-    assert _last_kernel() == "warp_fwd<NCHW>"                       # the literal kornia contract, mvdetr.py:194-195
+    assert _last_kernel() == "warp_fwd_nchw_patch"                  # the literal kornia contract, mvdetr.py:194-195 (fp32)
     warp(src.double(), M, (120, 360))
+    assert _last_kernel() == "warp_fwd<NCHW>"
+    warp(src[:, :, :, :158], M, (120, 360))                         # rows that are not whole 16-byte pieces
     assert _last_kernel() == "warp_fwd<NCHW>"
     warp(src, M, (120, 360), channels_last_out=True)
     assert _last_kernel() == "warp_fwd_cl"                          # after the tiled transpose
@@ -429,7 +431,7 @@ def test_stress16_size_forward_and_adjoint(warp):
     src = torch.randn(16, C, h, w, generator=torch.Generator().manual_seed(0))
     ref = c_oracle.warp_perspective(src.double(), M.float().double(), (H, W))
     a = warp(src.cuda(), M, (H, W))
-    assert _last_kernel() == "warp_fwd<NCHW>"
+    assert _last_kernel() == "warp_fwd_nchw_patch"
     assert (a.cpu().double() - ref).abs().max().item() < 1e-5
     src_cl = src.cuda().contiguous(memory_format=torch.channels_last)
     b = warp(src_cl, M, (H, W), channels_last_out=True)

@@ -7,3 +7,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $O/warp_trace -o t -- python $R/tools/microbench.py --iters 10 --only warp > /dev/null 2>&1
 cd $R; python tools/rocpd_summary.py $O/warp_trace/t_results.db | head -30
 rm -rf $O/warp_trace
+python tools/fuzz_warp.py --minutes ${FUZZ_MIN:-2} --seed 5 2>&1 | grep -v amdgpu.ids | tail -5
