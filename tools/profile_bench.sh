@@ -36,10 +36,12 @@ def avg(db, counter, kern):
     return sum(v) / len(v) if v else None
 out = {}
 # bench.py key -> the kernels of one call (per-launch averages are summed: a call launches each of them once)
-groups = {"msda_fwd": ["msda_fwd_group"], "warp_fwd": ["warp_fwd_cl<"], "warp_fwd_nchw": ["warp_fwd<"],
+groups = {"msda_fwd": ["msda_fwd_group"], "warp_fwd": ["warp_fwd_cl<"], "warp_fwd_nchw": ["warp_fwd_nchw_patch"],
           "warp_bwd": ["warp_bwd_scans", "warp_bwd_gather"],
-          "msda_bwd": ["msda_bwd_onepass<0", "msda_bwd_sampling"],
-          "msda_train": ["msda_fwd_group2<%7, 2, 2>", "msda_bwd_onepass<1", "msda_bwd_fused_sampling"]}
+          # (the grad_value-only instantiations: OnePassCfg<4, 16, 6, 0, ..>; the deterministic launch is OnePassCfg<.., 1, 8>, .., true>)
+          "msda_bwd": ["msda_bwd_onepass<0, mvdetr::OnePassCfg<4, 16, 6, 0", "msda_bwd_sampling"],
+          "msda_bwd_deterministic": ["msda_det_absmax", "msda_bwd_onepass<0, mvdetr::OnePassCfg<4, 16, 6, 1", "msda_det_finish"],
+          "msda_train": ["msda_fwd_group2<%7, 2, 2>", "msda_bwd_onepass<1, mvdetr::OnePassCfg<4, 16, 6, 0", "msda_bwd_fused_sampling"]}
 for key, kerns in groups.items():
     h = "_h" if key == "msda_fwd" else ""          # the headline kernel: the --headline-only passes
     f = [avg("$O/pmc_fetch" + h + "/p_results.db", "FETCH_SIZE", k) for k in kerns]
