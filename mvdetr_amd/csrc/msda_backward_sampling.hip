@@ -75,23 +75,6 @@ __device__ __forceinline__ void corners_from_memory(const float *__restrict__ vl
     corners_of_footprint<NV>(vlevel, row, W, footprint(y, x, H, W), rot, g, d00, d01, d10, d11);
 }
 
-// the same for a lane holding TWO chunks: chunk k of `g` is channels 4*((first + k)^rot)..+3
-__device__ __forceinline__ void corners_from_memory_half(const float *__restrict__ vlevel, int64_t row, int H, int W, float x,
-                                                         float y, int first, int rot, const float4 *g, f2 &d00, f2 &d01,
-                                                         f2 &d10, f2 &d11)
-{
-    const Footprint<float> f = footprint(y, x, H, W);
-    const float *r0 = vlevel + ((int64_t)f.y0 * W + f.x0) * row, *r1 = r0 + (int64_t)W * row;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int ko = ((first + k) ^ rot) << 2;
-        if (f.vy0 && f.vx0) d00 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + ko), d00);
-        if (f.vy0 && f.vx1) d01 = dot4(g[k], *reinterpret_cast<const float4 *>(r0 + row + ko), d01);
-        if (f.vy1 && f.vx0) d10 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + ko), d10);
-        if (f.vy1 && f.vx1) d11 = dot4(g[k], *reinterpret_cast<const float4 *>(r1 + row + ko), d11);
-    }
-}
-
 // ---- all source windows resident: D = 16, L <= 7 (MVDeTr's own shapes) ------------------------------------------------
 // msda_bwd_sampling_tile stages the L source windows once per QUERY level: 7 x 7 windows of 72 KB per 128 cells,
 // 1.35 GB of L2->LDS copies per launch at Wildtrack size, most of them L2 misses (FETCH_SIZE 1.18 GB) -- and between two
@@ -203,6 +186,7 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
         STRACE(tr + 4);
 
         float4 r_aw[RS_MAXL], r_l0[RS_MAXL], r_l1[RS_MAXL];
+        unsigned far_taps = 0u;                               // bit 4 l + p: in the image, outside the window (finished below)
 #pragma unroll
         for (int l = 0; l < RS_MAXL; ++l) {
             if (l >= L) continue;                             // (uniform; `break` would keep the loop from unrolling)
@@ -227,7 +211,9 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
                         q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D + D), q11);
                     }
                 } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {       // (lanes without a cell carry cell 0's taps)
-                    corners_from_memory_half(vbatch + lsi[l] * row, row, Hq, Wq, x, y, 2 * sub, rot, g, q00, q01, q10, q11);
+                    // no gathers between the taps' LDS reads (round 5): the tap is noted, its gradients are zeros here and are
+                    // written again by the list walk behind the job's stores
+                    far_taps |= 1u << (l * P + p);
                 }
                 float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
                 d00 += neighbour(d00);                        // the other half of the head sits in the neighbouring lane
@@ -253,6 +239,59 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
                 *reinterpret_cast<float4 *>(grad_aw + e0 + l * P) = r_aw[l];
                 *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2) = r_l0[l];
                 *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2 + 4) = r_l1[l];
+            }
+        }
+        // ---- taps outside their window: one list per lane (both half-head lanes of a (camera, cell) hold the same list), walked
+        //      with the NEXT entry's sampling data requested before the current entry's eight corner gathers -- a round trip per
+        //      far tap of the wave's worst lane.  (Inside the tap loop they cost a divergent round trip per tap with any far lane
+        //      in the wave: 326 -> 705 us for this kernel between offset spreads of 1 and 3 px.)  Same-lane program order puts
+        //      these stores behind the zeros written above.
+        if (far_taps) {
+            float2 nxy = make_float2(0.f, 0.f);
+            float na_ = 0.f;
+            int64_t nls = 0;
+            int nt = 0;
+            auto request = [&]() {
+                nt = __ffs((int)far_taps) - 1;
+                far_taps &= far_taps - 1u;
+                nxy = *reinterpret_cast<const float2 *>(loc + (e0 + nt) * 2);
+                na_ = aw[e0 + nt];
+                nls = lsi[nt >> 2];
+            };
+            request();
+            for (;;) {
+                const float2 xy = nxy;
+                const float a = na_;
+                const int t_ = nt;
+                const float *vlevel = vbatch + nls * row;
+                const bool more = far_taps != 0u;
+                if (more) request();
+                const float x = xy.x * fW - 0.5f, y = xy.y * fH - 0.5f;       // (the tap loop's expressions)
+                const Footprint<float> f = footprint(y, x, Hq, Wq);
+                const float *r0 = vlevel + ((int64_t)f.y0 * Wq + f.x0) * row, *r1 = r0 + (int64_t)Wq * row;
+                f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int ko = ((2 * sub + k) ^ rot) << 2;
+                    const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch), c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
+                    const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch), c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
+                    q00 = dot4(g[k], c00, q00);
+                    q01 = dot4(g[k], c01, q01);
+                    q10 = dot4(g[k], c10, q10);
+                    q11 = dot4(g[k], c11, q11);
+                }
+                float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+                d00 += neighbour(d00);
+                d01 += neighbour(d01);
+                d10 += neighbour(d10);
+                d11 += neighbour(d11);
+                const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                if (sub == 0) {
+                    grad_aw[e0 + t_] = wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11);
+                    *reinterpret_cast<float2 *>(grad_loc + (e0 + t_) * 2) =
+                        make_float2(fW * a * ((d01 - d00) * wy0 + (d11 - d10) * wy1), fH * a * ((d10 - d00) * wx0 + (d11 - d01) * wx1));
+                }
+                if (!more) break;
             }
         }
     }
