@@ -352,53 +352,69 @@ __global__ __launch_bounds__(Cfg::THREADS, 2) void msda_bwd_fused_sampling(
 
             // ---- taps of this level whose footprint left the window (rare): the same gradients from global memory; their
             // stores come after the stream's (which wrote zeros for them) in this lane's program order
-            if (__builtin_amdgcn_ballot_w64(mlevel != 0) != 0) {
-#pragma unroll
-                for (int c = 0; c < NG; ++c) {
-                    if (__builtin_amdgcn_ballot_w64((mlevel >> (c * P)) & 15u) == 0) continue;
-                    const int64_t q = (int64_t)cam_q(c) + cell;                      // inside the batch element
-                    const float *lp = rawb + q * raw_q + l * l_stride + hs * CHUNK + sub * P * 2;
-                    const float *wp = rawb + q * raw_q + l * l_stride + hs * CHUNK + HPS * P * 2 + sub * P;
-                    unsigned mm = (mlevel >> (c * P)) & 15u;
+            // ONE list per lane -- bit c P + p of `mlevel` -- walked with the NEXT entry's sampling data (raw offsets, logit,
+            // reference point, the camera's first token) requested before the current entry's gathers: a round trip per far tap
+            // of the wave's worst lane.  (Before: per camera with a miss anywhere in the wave, its sampling data and then the
+            // gathers -- two dependent round trips each, seven cameras per level.)
+            if (mlevel) {
+                unsigned ml = mlevel;
+                float2 nof = make_float2(0.f, 0.f), nrf = nof;
+                float nlg = 0.f;
+                int nt = 0, ncq = 0;
+                auto request = [&]() {
+                    nt = __ffs((int)ml) - 1;
+                    ml &= ml - 1u;
+                    const int c_ = nt >> 2, pp_ = nt & 3;
+                    ncq = (int)lsi[c_];
+                    const int64_t q_ = (int64_t)ncq + cell;                       // inside the batch element
+                    nof = *reinterpret_cast<const float2 *>(rawb + q_ * raw_q + l * l_stride + hs * CHUNK + sub * P * 2 + pp_ * 2);
+                    nlg = rawb[q_ * raw_q + l * l_stride + hs * CHUNK + HPS * P * 2 + sub * P + pp_];
+                    nrf = *reinterpret_cast<const float2 *>(ref + b * ref_bstride + ((int64_t)l * Lq + q_) * 2);
+                };
+                request();
+                for (;;) {
+                    const float2 of_ = nof, rf_ = nrf;
+                    const float lg_ = nlg;
+                    const int c = nt >> 2, pp = nt & 3, cq = ncq;
+                    const bool more = ml != 0u;
+                    if (more) request();
                     const float2 s = st_lane[Lds::st_row(c) / 2];
                     const float dq = dq_lane[c * NCL];
-                    const float *rp = ref + b * ref_bstride + ((int64_t)l * Lq + q) * 2;
-                    while (mm) {
-                        const int pp = __ffs((int)mm) - 1;
-                        mm &= mm - 1;
-                        float x, y, flx, fly, frx, fry;
-                        fused_px(rp[0], lp[pp * 2], fW, x, flx, frx);
-                        fused_px(rp[1], lp[pp * 2 + 1], fH, y, fly, fry);
-                        const float a = __expf(wp[pp] - s.x) * s.y;
-                        float dx = 0.f, dy = 0.f, da = 0.f;
-                        if (y > -1.f && x > -1.f && y < fH && x < fW) {
-                            const Footprint<float> f = footprint_split(fly, fry, flx, frx, Hq, Wq);
-                            const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * Wq + f.x0) * row;
-                            const float *r1 = r0 + (int64_t)Wq * row;
-                            float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
+                    const int64_t q = (int64_t)cq + cell;
+                    float x, y, flx, fly, frx, fry;
+                    fused_px(rf_.x, of_.x, fW, x, flx, frx);
+                    fused_px(rf_.y, of_.y, fH, y, fly, fry);
+                    const float a = __expf(lg_ - s.x) * s.y;
+                    float dx = 0.f, dy = 0.f, da = 0.f;
+                    if (y > -1.f && x > -1.f && y < fH && x < fW) {
+                        const Footprint<float> f = footprint_split(fly, fry, flx, frx, Hq, Wq);
+                        const float *r0 = vbatch + lsi[l] * row + lane_off + ((int64_t)f.y0 * Wq + f.x0) * row;
+                        const float *r1 = r0 + (int64_t)Wq * row;
+                        float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
 #pragma unroll
-                            for (int k = 0; k < NV; ++k) {
-                                const int ko = (k ^ rot) << 2;
-                                const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch), c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
-                                const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch), c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
-                                // (rare path: the camera's grad_out row comes from memory again, g_buf has moved on)
-                                const float4 gv = *reinterpret_cast<const float4 *>(go + ((int64_t)b * S + q) * row + head * D + ko);
-                                const float2v ga = {gv.x, gv.y}, gb = {gv.z, gv.w};
-                                d00 += (ga.x * c00.x + ga.y * c00.y) + (gb.x * c00.z + gb.y * c00.w);
-                                d01 += (ga.x * c01.x + ga.y * c01.y) + (gb.x * c01.z + gb.y * c01.w);
-                                d10 += (ga.x * c10.x + ga.y * c10.y) + (gb.x * c10.z + gb.y * c10.w);
-                                d11 += (ga.x * c11.x + ga.y * c11.y) + (gb.x * c11.z + gb.y * c11.w);
-                            }
-                            const float wx = f.wx1, wy = f.wy1;
-                            const float top = d00 + wx * (d01 - d00), bot = d10 + wx * (d11 - d10);
-                            da = top + wy * (bot - top);
-                            dx = (d01 - d00) + wy * ((d11 - d10) - (d01 - d00));
-                            dy = (d10 - d00) + wx * ((d11 - d01) - (d10 - d00));
+                        for (int k = 0; k < NV; ++k) {
+                            const int ko = (k ^ rot) << 2;
+                            const float4 c00 = load4_or_zero(r0 + ko, f.vy0 && f.vx0, vbatch), c01 = load4_or_zero(r0 + row + ko, f.vy0 && f.vx1, vbatch);
+                            const float4 c10 = load4_or_zero(r1 + ko, f.vy1 && f.vx0, vbatch), c11 = load4_or_zero(r1 + row + ko, f.vy1 && f.vx1, vbatch);
+                            // (rare path: the camera's grad_out row comes from memory again, g_buf has moved on)
+                            const float4 gv = *reinterpret_cast<const float4 *>(go + ((int64_t)b * S + q) * row + head * D + ko);
+                            const float2v ga = {gv.x, gv.y}, gb = {gv.z, gv.w};
+                            d00 += (ga.x * c00.x + ga.y * c00.y) + (gb.x * c00.z + gb.y * c00.w);
+                            d01 += (ga.x * c01.x + ga.y * c01.y) + (gb.x * c01.z + gb.y * c01.w);
+                            d10 += (ga.x * c10.x + ga.y * c10.y) + (gb.x * c10.z + gb.y * c10.w);
+                            d11 += (ga.x * c11.x + ga.y * c11.y) + (gb.x * c11.z + gb.y * c11.w);
                         }
-                        const unsigned so = (unsigned)(cam_q(c) * raw_q + l * l_stride) * 4u;
-                        buf_store2(rs_out, vo_l + pp * 8u, so, a * dx, a * dy);
-                        buf_store1(rs_out, vo_w + pp * 4u, so, a * (da - dq));
+                        const float wx = f.wx1, wy = f.wy1;
+                        const float top = d00 + wx * (d01 - d00), bot = d10 + wx * (d11 - d10);
+                        da = top + wy * (bot - top);
+                        dx = (d01 - d00) + wy * ((d11 - d10) - (d01 - d00));
+                        dy = (d10 - d00) + wx * ((d11 - d01) - (d10 - d00));
                     }
+                    // (the camera differs from lane to lane: its part of the address goes into the per-lane offset)
+                    const unsigned so_lane = (unsigned)(cq * raw_q + l * l_stride) * 4u;
+                    buf_store2(rs_out, vo_l + pp * 8u + so_lane, 0u, a * dx, a * dy);
+                    buf_store1(rs_out, vo_w + pp * 4u + so_lane, 0u, a * (da - dq));
+                    if (!more) break;
                 }
             }
         }
