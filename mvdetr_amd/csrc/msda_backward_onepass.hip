@@ -673,38 +673,57 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                             __builtin_amdgcn_wave_barrier();  // ... read by every lane before the next step's entries land
                         }
 
-                        // ---- taps outside the window (or every tap of a non-finite job): both halves straight from memory, the
-                        //      whole wave on one tap at a time with lanes = (corner, channel)
+                        // ---- taps outside the window (or every tap of a non-finite job): both halves straight from memory, FOUR
+                        //      taps per round with lanes = (tap of the round, channel) and the corners in turn -- an atomic
+                        //      instruction is four 64-byte segments, as when the whole wave took one tap with lanes = (corner,
+                        //      channel), but the shuffles, the footprint and the loop are paid once per four taps
                         const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
                         const bool miss = valid && (direct_only || !inw) && in_image;
                         unsigned long long pend = __ballot(miss);
                         while (pend) {
-                            const int src = __ffsll((long long)pend) - 1;
-                            pend &= pend - 1;
+                            int s_[4];
+                            bool h_[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                h_[u] = pend != 0ull;
+                                s_[u] = h_[u] ? __ffsll((long long)pend) - 1 : 0;
+                                pend &= pend - 1ull;                              // (0 stays 0)
+                            }
+                            const int tq = lane_o >> 4, j = lane_o & 15;
+                            const int src = tq == 0 ? s_[0] : tq == 1 ? s_[1] : tq == 2 ? s_[2] : s_[3];
+                            const bool mine = tq == 0 ? h_[0] : tq == 1 ? h_[1] : tq == 2 ? h_[2] : h_[3];
                             const float sa = __shfl(a, src, 64);
                             const float sfx = __shfl(fx, src, 64), sfy = __shfl(fy, src, 64), swx = __shfl(wx1, src, 64), swy = __shfl(wy1, src, 64);
                             const unsigned sg = (unsigned)__shfl((int)my_q, src, 64) * row_b;
-                            const int cr = lane_o >> 4, j = lane_o & 15;
                             const float gk = *reinterpret_cast<const float *>(go_b + (sg + (unsigned)j * 4u));
                             const Footprint<float> f = footprint_split(sfy, swy, sfx, swx, Hq, Wq);
-                            const int yy = f.y0 + (cr >> 1), xx = f.x0 + (cr & 1);
-                            const float wgt = ((cr >> 1) ? f.wy1 : f.wy0) * ((cr & 1) ? f.wx1 : f.wx0);
-                            const bool ok = (unsigned)yy < (unsigned)Hq && (unsigned)xx < (unsigned)Wq;
-                            const int64_t vo = level_base + ch0 + ((int64_t)(ok ? yy : 0) * Wq + (ok ? xx : 0)) * row + j;
-                            if (ok && !repeat) {
-                                const float c = wgt * (gk * sa);
-                                if (DET && fabsf(c) < INFINITY)
-                                    atomicAdd(reinterpret_cast<unsigned long long *>(det_acc + vo), (unsigned long long)__double2ll_rn(ldexp((double)c, det_s)));
-                                else        // (DET: NaN / inf sums do not depend on the order either)
-                                    atomicAdd(grad_value + vo, c);
+                            [[maybe_unused]] float prs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int cr = 0; cr < 4; ++cr) {
+                                const int yy = f.y0 + (cr >> 1), xx = f.x0 + (cr & 1);
+                                const float wgt = ((cr >> 1) ? f.wy1 : f.wy0) * ((cr & 1) ? f.wx1 : f.wx0);
+                                const bool ok = mine && (unsigned)yy < (unsigned)Hq && (unsigned)xx < (unsigned)Wq;
+                                const int64_t vo = level_base + ch0 + ((int64_t)(ok ? yy : 0) * Wq + (ok ? xx : 0)) * row + j;
+                                if (ok && !repeat) {
+                                    const float c = wgt * (gk * sa);
+                                    if (DET && fabsf(c) < INFINITY)
+                                        atomicAdd(reinterpret_cast<unsigned long long *>(det_acc + vo), (unsigned long long)__double2ll_rn(ldexp((double)c, det_s)));
+                                    else        // (DET: NaN / inf sums do not depend on the order either)
+                                        atomicAdd(grad_value + vo, c);
+                                }
+                                if constexpr (DOTS) {
+                                    const float vk = ok ? value[vo] : 0.f;
+                                    float pr = sum8(gk * vk);
+                                    pr += dpp_f<0x140>(pr);                       // row_mirror: the other eight lanes of the sixteen
+                                    prs[cr] = pr;
+                                }
                             }
                             if constexpr (DOTS) {
-                                const float vk = ok ? value[vo] : 0.f;
-                                float pr = gk * vk;
-#pragma unroll
-                                for (int o = 8; o > 0; o >>= 1) pr += __shfl_xor(pr, o, 64);
-                                const float e00 = __shfl(pr, 0, 64), e01 = __shfl(pr, 16, 64), e10 = __shfl(pr, 32, 64), e11 = __shfl(pr, 48, 64);
-                                if (lane_o == src) dv = make_float4(e00, e01, e10, e11);
+                                const int myslot = (h_[0] && lane_o == s_[0]) ? 0 : (h_[1] && lane_o == s_[1]) ? 1 : (h_[2] && lane_o == s_[2]) ? 2
+                                                 : (h_[3] && lane_o == s_[3]) ? 3 : -1;
+                                const int from = (myslot < 0 ? 0 : myslot) * 16;
+                                const float e00 = __shfl(prs[0], from, 64), e01 = __shfl(prs[1], from, 64), e10 = __shfl(prs[2], from, 64), e11 = __shfl(prs[3], from, 64);
+                                if (myslot >= 0) dv = make_float4(e00, e01, e10, e11);
                             }
                         }
 
