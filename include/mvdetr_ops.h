@@ -299,12 +299,17 @@ int mvdetr_msda_set_forward_impl(int impl);
  * kernels (fp32 atomics when LDS windows are flushed).  With on != 0, mvdetr_msda_backward_f32 and
  * mvdetr_msda_backward_fused_f32 sum grad_value in 64-bit fixed point with one binary point per call -- 38 bits below
  * max|grad_out| x max(1, max|attn_weight|) -- so the result is bit-identical run to run (grad_sampling_loc / grad_attn_weight have
- * one writer per element in every mode).  Costs a stream-ordered scratch of 8 bytes per value element and three small launches.
+ * one writer per element in every mode).  Costs a scratch of 8 bytes per value element, kept per (device, stream) between calls (mvdetr_msda_release_scratch), and three small launches.
  * Only deformable-encoder calls are served (fp32, 16-channel heads, equal level shapes, num_query == spatial_size,
  * spatial_size * num_levels * num_point < 2^24); every other call returns hipErrorNotSupported (801) while the mode is on, and
  * unequal level shapes (device data) fill grad_value with NaN.  Returns the previous state; the initial state comes from
  * MVDETR_MSDA_BWD_DETERMINISTIC=1. */
 int mvdetr_msda_set_backward_deterministic(int on);
+
+/* The deterministic mode keeps its 64-bit accumulators (8 bytes per value element) per (device, stream) between calls
+ * (hipMallocAsync on the call's stream, grown on demand).  This drops every cached buffer; call it when no backward is in flight.
+ * Not usable under HIP graph capture. */
+int mvdetr_msda_release_scratch(void);
 
 /* dst[n][c][r] = src[n][r][c]: layout change between NCHW (rows = channels, cols = h*w) and the channel-last layout the
  * fast warp kernels read, and back.  Tiled through LDS, both sides move in 256-byte runs. */

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mvdetr_msda_last_forward_resources": ([ctypes.POINTER(ctypes.c_int)] * 3, _i),
     "mvdetr_msda_set_forward_impl": ([_i], _i),
     "mvdetr_msda_set_backward_deterministic": ([_i], _i),
+    "mvdetr_msda_release_scratch": ([], _i),
     "mvdetr_warp_last_kernel": ([], ctypes.c_char_p),
     "mvdetr_warp_release_scratch": ([], _i),
     "mvdetr_msda_forward_f32": (_MSDA_FWD, _i),

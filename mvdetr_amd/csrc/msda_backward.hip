@@ -224,6 +224,8 @@ int mvdetr_msda_set_backward_deterministic(int on)
     return mvdetr::backward_deterministic().exchange(on ? 1 : 0);
 }
 
+int mvdetr_msda_release_scratch(void) { return mvdetr::msda_release_det_scratch(); }
+
 int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const float *value,
                                    const int64_t *spatial_shapes, const int64_t *level_start_index,
                                    const float *reference_points, int64_t ref_batch_stride, const float *raw,

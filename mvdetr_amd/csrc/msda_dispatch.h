@@ -89,6 +89,7 @@ bool msda_backward_deterministic_supported(int B, int S, int M, int D, int L, in
 int msda_backward_onepass_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
                               const float *loc, const float *aw, int B, int S, int M, int D, int L, float *grad_value,
                               float *grad_loc, float *grad_aw);
+int msda_release_det_scratch();
 int msda_backward_onepass_fused_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes,
                                     const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                     const float *stats, const float *out_fwd, int B, int S, int M, int D, int L,

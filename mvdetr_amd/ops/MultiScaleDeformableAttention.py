@@ -323,3 +323,9 @@ def set_backward_deterministic(on: bool) -> bool:
     summed in 64-bit fixed point instead of with fp32 atomics (the reference's atomicAdd, cuh:125-152, is not reproducible
     either).  Deformable-encoder calls only; any other backward raises while the mode is on.  Returns the previous state."""
     return bool(_lib.lib().mvdetr_msda_set_backward_deterministic(1 if on else 0))
+
+
+def release_scratch() -> None:
+    """Hand back the deterministic mode's cached accumulators (``mvdetr_msda_release_scratch``); call it when no backward is
+    in flight."""
+    _lib.check(_lib.lib().mvdetr_msda_release_scratch(), "release_scratch")

@@ -26,6 +26,8 @@ def deterministic(ops):
     prev = MSDA.set_backward_deterministic(True)
     yield MSDA
     MSDA.set_backward_deterministic(prev)
+    torch.cuda.synchronize()
+    MSDA.release_scratch()                                    # (the mode's accumulators are cached per stream between calls)
 
 
 def dev(*xs):
