@@ -84,7 +84,7 @@ int msda_backward_onepass_fused(hipStream_t st, const float *go, const float *va
                                 const float *stats, const float *out_fwd, int B, int S, int M, int D, int L,
                                 float *grad_value, float *grad_raw);
 // the same kernel with grad_value summed in 64-bit fixed point (one binary point per call): bit-reproducible run to run.  Opt-in
-// (mvdetr_msda_set_backward_deterministic / MVDETR_MSDA_BWD_DETERMINISTIC=1); stream-ordered scratch of 8 bytes per value element
+// (mvdetr_msda_set_backward_deterministic / MVDETR_MSDA_BWD_DETERMINISTIC=1); scratch of 8 bytes per value element, cached per (device, stream)
 bool msda_backward_deterministic_supported(int B, int S, int M, int D, int L, int64_t q_floats);
 int msda_backward_onepass_det(hipStream_t st, const float *go, const float *value, const int64_t *shapes, const int64_t *lsi,
                               const float *loc, const float *aw, int B, int S, int M, int D, int L, float *grad_value,
