@@ -158,12 +158,16 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
             // rounds 2-4's pair (and 32-channel heads): a stream-ordered scratch int carries the locality probe's verdict to both
             // kernels: calls whose taps are far from their queries (e.g. uniformly random locations) run the lane-group
             // backward inside the first launch instead -- no host synchronisation
+            // (no probe means something else to the sampling kernels -- "take your own sample and skip the tiles the grad_value
+            // kernel has taken along" -- and this path's grad_value kernel never takes a tile along: an allocation failure is
+            // returned, not papered over)
             int *hits = nullptr;
-            if (hipMallocAsync(reinterpret_cast<void **>(&hits), MSDA_PROBE_INTS * sizeof(int), st) != hipSuccess) hits = nullptr;
-            int rc = hits ? msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits) : 0;
+            const hipError_t arc = hipMallocAsync(reinterpret_cast<void **>(&hits), MSDA_PROBE_INTS * sizeof(int), st);
+            if (arc != hipSuccess || !hits) return (int)(arc != hipSuccess ? arc : hipErrorOutOfMemory);
+            int rc = msda_launch_locality_probe(st, loc, shapes, B, S, M, L, hits);
             if (!rc) rc = msda_backward_value_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_value, grad_loc, grad_aw, hits);
             if (!rc) rc = msda_backward_sampling_tile(st, grad_col, value, shapes, lsi, loc, aw, B, S, M, D, L, grad_loc, grad_aw, hits);
-            if (hits) (void)hipFreeAsync(hits, st);
+            (void)hipFreeAsync(hits, st);
             return rc;
         }
     }

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
     const int64_t j_end = spread ? band : total_jobs * (rank + 1) / nwg;
     const int64_t j_step = spread ? (nwg >> 3) : 0;
     [[maybe_unused]] int job_no = 0;
+    float Wprev = 0.f;                                        // the weight mass the workgroup's previous job measured (any unit)
     for (int64_t j = j_begin; j < j_end;) {
         const int64_t jj = spread ? ((int64_t)blockIdx.x & 7) * band + j : j;
         if (spread) {
@@ -346,15 +347,41 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
         };
         if constexpr (DOTS) issue_dma(l_first);
 
-        float Gmax_u = 0.f, Wprev = 0.f;                      // the unit's largest |grad_out|; the previous level's weight mass
+        // ---- the unit's largest |grad_out| (inf if any is not finite): one pass over the (cell, camera) items' 64-byte rows of
+        //      this head, lanes = items.  With it every level job of the unit can GUESS its fixed-point scale (below) -- also the
+        //      unit's first: the weight mass per token is a statistic of the call, not of the (tile, head), so the guess builds on
+        //      whatever job the workgroup ran last.  Only a workgroup's very first job pays the exact bound pass.
+        float Gmax_u = 0.f;
+        if (Wprev > 0.f && Wprev < INFINITY) {
+            int tid_u = tid;
+            asm volatile("" : "+v"(tid_u));
+            float gm = 0.f;
+            for (int it = tid_u; it < CELLS * L; it += THREADS) {
+                const int ci = it % CELLS, c = it / CELLS;
+                const int qy = Y0 + ci / TW, qx = X0 + ci % TW;
+                const bool ok = qy < Hq && qx < Wq;
+                const float *gp = go + ((int64_t)b * S + lsi[c] + (ok ? (int64_t)qy * Wq + qx : 0)) * row + ch0;
+                float m = 0.f;
+#pragma unroll
+                for (int j4 = 0; j4 < LCH; j4 += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(gp + j4);
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    if (!(v.x == v.x && v.y == v.y && v.z == v.z && v.w == v.w)) m = INFINITY;     // NaN
+                }
+                if (ok) gm = fmaxf(gm, m);
+            }
+            float unused_u = 0.f;
+            block_max2(gm, unused_u);
+            Gmax_u = gm;
+        }
         for (int l = l_first; l < l_last; ++l) {
             [[maybe_unused]] const int tr = tr0 + (l - l_first) * 64;
             if (l > l_first) OTRACE(tr + 0);
             const int64_t level_base = ((int64_t)b * S + lsi[l]) * row;
-            // `guess`: the fixed-point scale from the unit's Gmax and twice the previous level's measured weight mass, no bound
+            // `guess`: the fixed-point scale from the unit's Gmax and twice the previous job's measured weight mass, no bound
             // pass; the job measures its own mass (each add rounded up and clamped to MASS_CLAMP, so that neither a wrap nor a
             // single huge weight can hide an overflow) and is repeated exactly if that exceeds the guess
-            bool guess = l > l_first && Wprev > 0.f && Wprev < INFINITY && Gmax_u > 0.f && Gmax_u < INFINITY;
+            bool guess = Wprev > 0.f && Wprev < INFINITY && Gmax_u > 0.f && Gmax_u < INFINITY;
             float Wmax = 0.f, scale = 0.f, inv_scale = 0.f, mscale = 0.f;
             [[maybe_unused]] int e_job = 0;                   // the job's fixed point: steps of 2^(e_job - 30)
             bool direct_only = false, no_scatter = false;
@@ -502,8 +529,13 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                     ga_b = reinterpret_cast<char *>(grad_aw + (int64_t)b * S * M * L * P);
                     loc_q = (unsigned)(M * L * P * 2) * 4u;
                     aw_q = (unsigned)(M * L * P) * 4u;
+#ifdef MVDETR_EXP_SAMELEVEL      // timing experiment (wrong results): every level job reads level 0's sampling lines
+                    loc_c = (unsigned)((head * L + 0) * P * 2 + pp * 2) * 4u;
+                    aw_c = (unsigned)((head * L + 0) * P + pp) * 4u;
+#else
                     loc_c = (unsigned)((head * L + l) * P * 2 + pp * 2) * 4u;
                     aw_c = (unsigned)((head * L + l) * P + pp) * 4u;
+#endif
                 }
 
                 unsigned cam_q[CAMS];                             // first token of the pass's cameras (uniform)

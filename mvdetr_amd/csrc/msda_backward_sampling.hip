@@ -22,6 +22,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef MVDETR_RS_DEPTH
+#define MVDETR_RS_DEPTH 2     // msda_bwd_sampling_resident: taps whose corner reads are in flight ahead of the tap being finished
+#endif
+#ifndef MVDETR_RS_LATE
+#define MVDETR_RS_LATE 7      // ... and the first level whose sampling data is requested late (7 = none)
+#endif
+
 #ifdef MVDETR_BWD_TRACE
 // tuning aid (never in the shipped build): 100 MHz wall-clock stamps of one workgroup's waves
 __device__ unsigned long long g_bws_trace[2048];
@@ -174,73 +181,100 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
         for (int k = 0; k < NV; ++k) g[k] = *reinterpret_cast<const float4 *>(go + q * row + head * D + (((2 * sub + k) ^ rot) << 2));
         // the (query, head)'s sampling data of all levels: one contiguous run each
         float4 la[RS_MAXL], lb[RS_MAXL], wa[RS_MAXL];
+        auto load_levels = [&](int l0, int l1) {
 #pragma unroll
-        for (int l = 0; l < RS_MAXL; ++l) {
-            const int ll = l < L ? l : L - 1;
-            la[l] = *reinterpret_cast<const float4 *>(loc + (e0 + ll * P) * 2);
-            lb[l] = *reinterpret_cast<const float4 *>(loc + (e0 + ll * P) * 2 + 4);
-            wa[l] = *reinterpret_cast<const float4 *>(aw + e0 + ll * P);
-        }
+            for (int l = 0; l < RS_MAXL; ++l) {
+                if (l < l0 || l >= l1) continue;
+                const int ll = l < L ? l : L - 1;
+                la[l] = *reinterpret_cast<const float4 *>(loc + (e0 + ll * P) * 2);
+                lb[l] = *reinterpret_cast<const float4 *>(loc + (e0 + ll * P) * 2 + 4);
+                wa[l] = *reinterpret_cast<const float4 *>(aw + e0 + ll * P);
+            }
+        };
+        load_levels(0, MVDETR_RS_LATE);
         STRACE(tr + 3);
         __syncthreads();                                      // the windows have landed
         STRACE(tr + 4);
 
-        float4 r_aw[RS_MAXL], r_l0[RS_MAXL], r_l1[RS_MAXL];
         unsigned far_taps = 0u;                               // bit 4 l + p: in the image, outside the window (finished below)
+        // The taps as a software pipeline: the eight corner reads (4 corners x 2 chunks of 16 bytes) of the next DEPTH - 1 taps
+        // are in flight while a tap's dots are taken, across level boundaries -- with two waves per SIMD the LDS round trip of
+        // a tap (longer under bank conflicts: neighbouring cells' taps are displaced at random) was exposed 28 times per job
+        // (round 5: 336 us; DEPTH 2: 284 us).  A tap outside its window reads window token 0 and its dots are discarded.  A
+        // level's gradients leave as soon as its four taps are complete: the 336-byte run of a (query, head) is written within
+        // one job, 48 bytes at a time, and merges in L2; holding all levels' results until the end cost 84 registers.
+        constexpr int DEPTH = MVDETR_RS_DEPTH;
+        float4 cbuf[DEPTH][8];
+        float tx_[DEPTH], ty_[DEPTH];
+        bool tin_[DEPTH];
+        auto issue = [&](int l, int p, int s_) {
+            const float lx = p == 0 ? la[l].x : p == 1 ? la[l].z : p == 2 ? lb[l].x : lb[l].z;
+            const float ly = p == 0 ? la[l].y : p == 1 ? la[l].w : p == 2 ? lb[l].y : lb[l].w;
+            const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
+            const bool in = fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1);
+            const int ix = in ? (int)floorf(x) - ox : 0, iy = in ? (int)floorf(y) - oy : 0;
+            const float *p00 = vwin + l * NTOK * D + (iy * WW + ix) * D;
 #pragma unroll
-        for (int l = 0; l < RS_MAXL; ++l) {
-            if (l >= L) continue;                             // (uniform; `break` would keep the loop from unrolling)
-            const float *wl = vwin + l * NTOK * D;
-            const float xs[4] = {la[l].x * fW - 0.5f, la[l].z * fW - 0.5f, lb[l].x * fW - 0.5f, lb[l].z * fW - 0.5f};
-            const float ys[4] = {la[l].y * fH - 0.5f, la[l].w * fH - 0.5f, lb[l].y * fH - 0.5f, lb[l].w * fH - 0.5f};
-            const float as[4] = {wa[l].x, wa[l].y, wa[l].z, wa[l].w};
-            float ga[4], gx[4], gy[4];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const float x = xs[p], y = ys[p];
-                f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
-                if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
-                    const int ix = (int)floorf(x) - ox, iy = (int)floorf(y) - oy;
-                    const float *p00 = wl + (iy * WW + ix) * D;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        const float *pk = p00 + (((2 * sub + k) ^ rot) << 2);
-                        q00 = dot4(g[k], *reinterpret_cast<const float4 *>(pk), q00);
-                        q01 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + D), q01);
-                        q10 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D), q10);
-                        q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D + D), q11);
-                    }
-                } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {       // (lanes without a cell carry cell 0's taps)
-                    // no gathers between the taps' LDS reads (round 5): the tap is noted, its gradients are zeros here and are
-                    // written again by the list walk behind the job's stores
-                    far_taps |= 1u << (l * P + p);
-                }
-                float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
-                d00 += neighbour(d00);                        // the other half of the head sits in the neighbouring lane
-                d01 += neighbour(d01);
-                d10 += neighbour(d10);
-                d11 += neighbour(d11);
-                const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
-                ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
-                gx[p] = in_image ? fW * as[p] * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-                gy[p] = in_image ? fH * as[p] * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
-                __builtin_amdgcn_sched_barrier(0);            // one tap's 16 LDS reads in flight at a time
+            for (int k = 0; k < NV; ++k) {
+                const float *pk = p00 + (((2 * sub + k) ^ rot) << 2);
+                cbuf[s_][4 * k + 0] = *reinterpret_cast<const float4 *>(pk);
+                cbuf[s_][4 * k + 1] = *reinterpret_cast<const float4 *>(pk + D);
+                cbuf[s_][4 * k + 2] = *reinterpret_cast<const float4 *>(pk + WW * D);
+                cbuf[s_][4 * k + 3] = *reinterpret_cast<const float4 *>(pk + WW * D + D);
             }
-            r_aw[l] = make_float4(ga[0], ga[1], ga[2], ga[3]);
-            r_l0[l] = make_float4(gx[0], gy[0], gx[1], gy[1]);
-            r_l1[l] = make_float4(gx[2], gy[2], gx[3], gy[3]);
+            tx_[s_] = x;
+            ty_[s_] = y;
+            tin_[s_] = in;
+        };
+        float ga[4], gx[4], gy[4];
+        auto finish = [&](int l, int p, int s_) {
+            const float x = tx_[s_], y = ty_[s_];
+            const float a = p == 0 ? wa[l].x : p == 1 ? wa[l].y : p == 2 ? wa[l].z : wa[l].w;
+            f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                q00 = dot4(g[k], cbuf[s_][4 * k + 0], q00);
+                q01 = dot4(g[k], cbuf[s_][4 * k + 1], q01);
+                q10 = dot4(g[k], cbuf[s_][4 * k + 2], q10);
+                q11 = dot4(g[k], cbuf[s_][4 * k + 3], q11);
+            }
+            float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+            d00 += neighbour(d00);                            // the other half of the head sits in the neighbouring lane
+            d01 += neighbour(d01);
+            d10 += neighbour(d10);
+            d11 += neighbour(d11);
+            const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
+            if (!tin_[s_]) {
+                // no gathers between the taps' LDS reads (round 5): the tap is noted, its gradients are zeros here and are
+                // written again by the list walk behind the job's stores
+                d00 = d01 = d10 = d11 = 0.f;
+                if (active && in_image) far_taps |= 1u << (l * P + p);      // (lanes without a cell carry cell 0's taps)
+            }
+            const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+            ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
+            gx[p] = in_image ? fW * a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+            gy[p] = in_image ? fH * a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+            if (p == P - 1 && active && sub == 0) {
+                *reinterpret_cast<float4 *>(grad_aw + e0 + l * P) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2) = make_float4(gx[0], gy[0], gx[1], gy[1]);
+                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2 + 4) = make_float4(gx[2], gy[2], gx[3], gy[3]);
+            }
+        };
+#pragma unroll
+        for (int t_ = 0; t_ < DEPTH - 1; ++t_)
+            if (t_ / P < L) issue(t_ / P, t_ % P, t_ % DEPTH);
+#pragma unroll
+        for (int t_ = 0; t_ < RS_MAXL * P; ++t_) {
+            const int l = t_ / P, p = t_ % P, tn = t_ + DEPTH - 1;
+            if (l >= L) continue;                             // (uniform; `break` would keep the loop from unrolling)
+            // (the late levels' sampling data: requested once the first level is done, needed MVDETR_RS_LATE - 1 levels later)
+            if (MVDETR_RS_LATE < RS_MAXL && t_ == P) load_levels(MVDETR_RS_LATE, RS_MAXL);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tn < RS_MAXL * P && tn / P < L) issue(tn / P, tn % P, tn % DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            finish(l, p, t_ % DEPTH);
         }
         STRACE(tr + 5);
-        if (active && sub == 0) {
-#pragma unroll
-            for (int l = 0; l < RS_MAXL; ++l) {
-                if (l >= L) continue;
-                *reinterpret_cast<float4 *>(grad_aw + e0 + l * P) = r_aw[l];
-                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2) = r_l0[l];
-                *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2 + 4) = r_l1[l];
-            }
-        }
         // ---- taps outside their window: one list per lane (both half-head lanes of a (camera, cell) hold the same list), walked
         //      with the NEXT entry's sampling data requested before the current entry's eight corner gathers -- a round trip per
         //      far tap of the wave's worst lane.  (Inside the tap loop they cost a divergent round trip per tap with any far lane
