@@ -473,83 +473,150 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
                     dq += neighbour(dq);
                 }
                 if (c0 == 0) __syncthreads();                 // the group's windows have landed
-                float4 r_aw[LG], r_l0[LG], r_l1[LG];
-#pragma unroll
-                for (int j = 0; j < LG; ++j) {
-                    if (j >= ng) continue;                    // (uniform)
-                    const float *wl = vwin + j * NTOK * D;
-                    // (FUSED: offsets in pixels; the position is formed in two parts, common.h fused_px)
-                    const float lxs[4] = {la[j].x, la[j].z, lb[j].x, lb[j].z}, lys[4] = {la[j].y, la[j].w, lb[j].y, lb[j].w};
-                    const float as[4] = {wa[j].x, wa[j].y, wa[j].z, wa[j].w};
-                    float ga[4], gx[4], gy[4];
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        float x, y, fx, fy, wx1, wy1, a;
-                        if constexpr (FUSED) {
-                            fused_px(rf[j].x, lxs[p], fW, x, fx, wx1);
-                            fused_px(rf[j].y, lys[p], fH, y, fy, wy1);
-                            a = __expf(as[p] - st.x) * st.y;
-                        } else {
-                            x = lxs[p] * fW - 0.5f;
-                            y = lys[p] * fH - 0.5f;
-                            fx = floorf(x);
-                            fy = floorf(y);
-                            wx1 = x - fx;
-                            wy1 = y - fy;
-                            a = as[p];
-                        }
-                        f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
-                        if (fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1)) {
-                            const int ix = (int)fx - ox, iy = (int)fy - oy;
-                            const float *p00 = wl + (iy * WW + ix) * D + sub * HALF;
-#pragma unroll
-                            for (int k = 0; k < NV; ++k) {
-                                const float *pk = p00 + ((k ^ rot) << 2);
-                                q00 = dot4(g[k], *reinterpret_cast<const float4 *>(pk), q00);
-                                q01 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + D), q01);
-                                q10 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D), q10);
-                                q11 = dot4(g[k], *reinterpret_cast<const float4 *>(pk + WW * D + D), q11);
-                            }
-                        } else if (active && y > -1.f && x > -1.f && y < fH && x < fW) {   // (lanes without a cell carry cell 0's taps)
-                            corners_of_footprint<NV>(vbatch + lsi[g0 + j] * row + sub * HALF, row, Wq, footprint_split(fy, wy1, fx, wx1, Hq, Wq),
-                                                     rot, g, q00, q01, q10, q11);
-                        }
-                        float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
-                        d00 += neighbour(d00);                // the other half of the head sits in the neighbouring lane
-                        d01 += neighbour(d01);
-                        d10 += neighbour(d10);
-                        d11 += neighbour(d11);
-                        const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                        const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
-                        const float da = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
-                        if constexpr (FUSED) {
-                            // (a tap outside the image still has a logit: its weight takes part in the softmax)
-                            ga[p] = a * (da - dq);
-                            gx[p] = in_image ? a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-                            gy[p] = in_image ? a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
-                        } else {
-                            ga[p] = da;
-                            gx[p] = in_image ? fW * a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-                            gy[p] = in_image ? fH * a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);    // one tap's LDS reads in flight at a time
+                // The group's taps -- ng levels x 4 points -- as a two-stage software pipeline, as in msda_bwd_sampling_resident:
+                // tap t + 1's corner reads (4 corners x NV chunks of 16 bytes) are in flight while tap t's dots are taken.  A tap
+                // outside its window reads window token 0, its dots are discarded and it is noted in `far_taps` (bit 4 j + p),
+                // finished from global memory by the list walk behind the stream; a level's gradients leave as soon as its four
+                // taps are complete.
+                unsigned far_taps = 0u;
+                float4 cbuf[2][4 * NV];
+                // position of tap (level j of the group, point p_): pixel coordinates, their floors, the far corner's weights and
+                // the window test -- evaluated when the tap's reads are issued AND when it is finished (the same expressions give
+                // the same bits; carrying them through the pipeline cost registers the 32-channel instantiation does not have)
+                auto tap_pos = [&](int j, int p_, float &x, float &y, float &fx, float &fy, float &wx1, float &wy1) {
+                    const float lx = p_ == 0 ? la[j].x : p_ == 1 ? la[j].z : p_ == 2 ? lb[j].x : lb[j].z;
+                    const float ly = p_ == 0 ? la[j].y : p_ == 1 ? la[j].w : p_ == 2 ? lb[j].y : lb[j].w;
+                    if constexpr (FUSED) {
+                        // (offsets in pixels; the position is formed in two parts, common.h fused_px)
+                        fused_px(rf[j].x, lx, fW, x, fx, wx1);
+                        fused_px(rf[j].y, ly, fH, y, fy, wy1);
+                    } else {
+                        x = lx * fW - 0.5f;
+                        y = ly * fH - 0.5f;
+                        fx = floorf(x);
+                        fy = floorf(y);
+                        wx1 = x - fx;
+                        wy1 = y - fy;
                     }
-                    r_aw[j] = make_float4(ga[0], ga[1], ga[2], ga[3]);
-                    r_l0[j] = make_float4(gx[0], gy[0], gx[1], gy[1]);
-                    r_l1[j] = make_float4(gx[2], gy[2], gx[3], gy[3]);
-                }
-                if (active && sub == 0) {
+                    return fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1);
+                };
+                auto issue = [&](int j, int p_, int s_) {
+                    float x, y, fx, fy, wx1, wy1;
+                    const bool in = tap_pos(j, p_, x, y, fx, fy, wx1, wy1);
+                    const int ix = in ? (int)fx - ox : 0, iy = in ? (int)fy - oy : 0;
+                    const float *p00 = vwin + j * NTOK * D + (iy * WW + ix) * D + sub * HALF;
 #pragma unroll
-                    for (int j = 0; j < LG; ++j) {
-                        if (j >= ng) continue;
+                    for (int k = 0; k < NV; ++k) {
+                        const float *pk = p00 + ((k ^ rot) << 2);
+                        cbuf[s_][4 * k + 0] = *reinterpret_cast<const float4 *>(pk);
+                        cbuf[s_][4 * k + 1] = *reinterpret_cast<const float4 *>(pk + D);
+                        cbuf[s_][4 * k + 2] = *reinterpret_cast<const float4 *>(pk + WW * D);
+                        cbuf[s_][4 * k + 3] = *reinterpret_cast<const float4 *>(pk + WW * D + D);
+                    }
+                };
+                // the three gradients of one tap from its four dots (public contract: grad_attn_weight, grad_sampling_loc; FUSED:
+                // logit, offsets -- a tap outside the image still has a logit: its weight takes part in the softmax)
+                auto tap_grads = [&](float d00, float d01, float d10, float d11, float wx1, float wy1, float a, bool in_image, float &ga_,
+                                     float &gx_, float &gy_) {
+                    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+                    const float da = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
+                    if constexpr (FUSED) {
+                        ga_ = a * (da - dq);
+                        gx_ = in_image ? a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+                        gy_ = in_image ? a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                    } else {
+                        ga_ = da;
+                        gx_ = in_image ? fW * a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
+                        gy_ = in_image ? fH * a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                    }
+                };
+                float ga[4], gx[4], gy[4];
+                auto finish = [&](int j, int p_, int s_) {
+                    float x, y, fx_, fy_, wx1, wy1;
+                    const bool in = tap_pos(j, p_, x, y, fx_, fy_, wx1, wy1);
+                    float a = p_ == 0 ? wa[j].x : p_ == 1 ? wa[j].y : p_ == 2 ? wa[j].z : wa[j].w;
+                    if constexpr (FUSED) a = __expf(a - st.x) * st.y;
+                    f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        q00 = dot4(g[k], cbuf[s_][4 * k + 0], q00);
+                        q01 = dot4(g[k], cbuf[s_][4 * k + 1], q01);
+                        q10 = dot4(g[k], cbuf[s_][4 * k + 2], q10);
+                        q11 = dot4(g[k], cbuf[s_][4 * k + 3], q11);
+                    }
+                    float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+                    d00 += neighbour(d00);                    // the other half of the head sits in the neighbouring lane
+                    d01 += neighbour(d01);
+                    d10 += neighbour(d10);
+                    d11 += neighbour(d11);
+                    const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
+                    if (!in) {
+                        d00 = d01 = d10 = d11 = 0.f;
+                        if (active && in_image) far_taps |= 1u << (j * P + p_);      // (lanes without a cell carry cell 0's taps)
+                    }
+                    tap_grads(d00, d01, d10, d11, wx1, wy1, a, in_image, ga[p_], gx[p_], gy[p_]);
+                    if (p_ == P - 1 && active && sub == 0) {
                         if constexpr (FUSED) {
-                            *reinterpret_cast<float4 *>(grad_loc + w0_ + (g0 + j) * l_stride) = r_aw[j];
-                            *reinterpret_cast<float4 *>(grad_loc + r0_ + (g0 + j) * l_stride) = r_l0[j];
-                            *reinterpret_cast<float4 *>(grad_loc + r0_ + (g0 + j) * l_stride + 4) = r_l1[j];
+                            *reinterpret_cast<float4 *>(grad_loc + w0_ + (g0 + j) * l_stride) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+                            *reinterpret_cast<float4 *>(grad_loc + r0_ + (g0 + j) * l_stride) = make_float4(gx[0], gy[0], gx[1], gy[1]);
+                            *reinterpret_cast<float4 *>(grad_loc + r0_ + (g0 + j) * l_stride + 4) = make_float4(gx[2], gy[2], gx[3], gy[3]);
                         } else {
-                            *reinterpret_cast<float4 *>(grad_aw + e0 + j * P) = r_aw[j];
-                            *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2) = r_l0[j];
-                            *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2 + 4) = r_l1[j];
+                            *reinterpret_cast<float4 *>(grad_aw + e0 + j * P) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+                            *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2) = make_float4(gx[0], gy[0], gx[1], gy[1]);
+                            *reinterpret_cast<float4 *>(grad_loc + (e0 + j * P) * 2 + 4) = make_float4(gx[2], gy[2], gx[3], gy[3]);
+                        }
+                    }
+                };
+                issue(0, 0, 0);
+#pragma unroll
+                for (int t_ = 0; t_ < LG * P; ++t_) {
+                    const int j = t_ / P, p_ = t_ % P;
+                    if (j >= ng) continue;                    // (uniform)
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t_ + 1 < LG * P && (t_ + 1) / P < ng) issue((t_ + 1) / P, (t_ + 1) % P, (t_ + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(j, p_, t_ & 1);
+                }
+                // ---- taps outside their window: one list per lane (both half-head lanes of a (camera, cell) hold the same list),
+                //      the tap's sampling data read again (the registers cannot be indexed by a run-time tap), its corners gathered
+                //      from global memory with zero padding; same-lane program order puts these stores behind the zeros above
+                while (far_taps) {
+                    const int t_ = __ffs((int)far_taps) - 1, j = t_ >> 2, p_ = t_ & 3;
+                    far_taps &= far_taps - 1u;
+                    float x, y, fx, fy, wx1, wy1, a;
+                    if constexpr (FUSED) {
+                        const float2 o = *reinterpret_cast<const float2 *>(loc + r0_ + (g0 + j) * l_stride + p_ * 2);
+                        const float2 r = *reinterpret_cast<const float2 *>(ref + b * ref_bstride + ((int64_t)(g0 + j) * S + (q - (int64_t)b * S)) * 2);
+                        fused_px(r.x, o.x, fW, x, fx, wx1);
+                        fused_px(r.y, o.y, fH, y, fy, wy1);
+                        a = __expf(loc[w0_ + (g0 + j) * l_stride + p_] - st.x) * st.y;
+                    } else {
+                        const float2 o = *reinterpret_cast<const float2 *>(loc + (e0 + t_) * 2);
+                        x = o.x * fW - 0.5f;                  // (the stream's expressions)
+                        y = o.y * fH - 0.5f;
+                        fx = floorf(x);
+                        fy = floorf(y);
+                        wx1 = x - fx;
+                        wy1 = y - fy;
+                        a = aw[e0 + t_];
+                    }
+                    f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
+                    corners_of_footprint<NV>(vbatch + lsi[g0 + j] * row + sub * HALF, row, Wq, footprint_split(fy, wy1, fx, wx1, Hq, Wq), rot, g,
+                                             q00, q01, q10, q11);
+                    float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+                    d00 += neighbour(d00);
+                    d01 += neighbour(d01);
+                    d10 += neighbour(d10);
+                    d11 += neighbour(d11);
+                    float ga1, gx1, gy1;
+                    tap_grads(d00, d01, d10, d11, wx1, wy1, a, true, ga1, gx1, gy1);
+                    if (sub == 0) {
+                        if constexpr (FUSED) {
+                            grad_loc[w0_ + (g0 + j) * l_stride + p_] = ga1;
+                            *reinterpret_cast<float2 *>(grad_loc + r0_ + (g0 + j) * l_stride + p_ * 2) = make_float2(gx1, gy1);
+                        } else {
+                            grad_aw[e0 + t_] = ga1;
+                            *reinterpret_cast<float2 *>(grad_loc + (e0 + t_) * 2) = make_float2(gx1, gy1);
                         }
                     }
                 }
