@@ -80,7 +80,7 @@ def parse():
                     help="skip roofline_warp / roofline_warp_bwd / roofline_msda_bwd (measured after the timed region)")
     ap.add_argument("--no-gemm-tuning", action="store_true",
                     help="keep hipBLASLt's default solution per GEMM instead of PyTorch TunableOp's measured pick")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0)
     ap.add_argument("--msda-impl", default="auto", choices=["auto", "gather", "tile"])
     ap.add_argument("--offset-std-px", type=float, default=1.0,
                     help="std of the seeded perturbation of the learned sampling offsets, in pixels (SURVEY 8d: bias grid + "
@@ -275,9 +275,8 @@ def other_kernel_rooflines(model, geom, feat, proj, MSDA, launches=12):
         bbytes = 4 * (S * M_ * D_ + 2 * S * M_ * D_ + 6 * S * M_ * N * 4)   # 4 (Lq M D + 2 S M D + 6 Lq M L P)
         us, mn = time_launches(lambda: MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, aw, gout, 64), launches)
         out["roofline_msda_bwd"] = roofline_entry(
-            "msda_bwd_onepass<grad_value only> + msda_bwd_sampling_resident (+ memset of grad_value; no probe launch)" if (D_ == 16 and N <= 7)
-            else "msda_bwd_onepass<grad_value only> + msda_bwd_sampling_groups (+ memset of grad_value)" if D_ == 16
-            else "msda_bwd_value_tok + msda_bwd_sampling_groups (+ locality probe, memset of grad_value)", us, mn, bbytes, launches,
+            "msda_locality_probe + msda_bwd_value_tok + msda_bwd_sampling_resident (+ memset of grad_value)" if (D_ == 16 and N <= 7)
+            else "msda_locality_probe + msda_bwd_value_tok + msda_bwd_sampling_groups (+ memset of grad_value)", us, mn, bbytes, launches,
             "MultiScaleDeformableAttention.ms_deform_attn_backward (public contract), SURVEY 8d's locality-realistic input: "
             "bias grid + N(0, 1 px) offsets, softmax(N(0,1)) weights")
         if D_ == 16:
@@ -406,16 +405,20 @@ def cpu_baseline(model, imgs_cpu, proj_cpu, budget_s):
             frame_oracle.forward(p, imgs_cpu, proj_cpu, model.Rworld_shape, ref, model.num_cam)
         return time.perf_counter() - t0
 
-    times = [frame()]                                       # warm-up, kept only if there is no time for more
-    if times[0] < budget_s / 3:
-        times = []
-        while len(times) < 3 and sum(times) + (times[-1] if times else 0) <= budget_s:
-            times.append(frame())
-        times = times or [frame()]
+    # one warm-up frame, then up to three timed ones (a median, not one sample) while they fit the budget; a
+    # frame longer than the whole budget leaves the warm-up frame as the only sample -- the `sample` string says which it was
+    warm = frame()
+    times = []
+    while len(times) < 3 and (sum(times) + max(times) if times else warm) <= budget_s:
+        times.append(frame())
+    warm_only = not times
+    times = times or [warm]
     med = sorted(times)[len(times) // 2]
     return {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": best, "kind": "port",
             "sample": f"median of {len(times)} whole frame(s) ({model.num_cam} views 3x{imgs_cpu.shape[-2]}x{imgs_cpu.shape[-1]} -> BEV) "
-                      f"through oracle/frame_oracle.py on {best} thread(s) after a warm-up frame, {sum(times):.1f} s; thread count chosen by the "
+                      f"through oracle/frame_oracle.py on {best} thread(s) "
+                      + ("(the warm-up frame itself: it alone exceeded --cpu-budget-s)" if warm_only else "after a warm-up frame")
+                      + f", {sum(times):.1f} s timed within a budget of {budget_s:.0f} s; thread count chosen by the "
                       f"sweep below (hot ops on one camera's share, 2 warm-ups + median of 3)",
             "host": {"logical_cpus": logical, "physical_cores": physical}, "thread_sweep": {str(k): v for k, v in sweep.items()}}
 
@@ -753,9 +756,21 @@ def main():
                           ("roofline_train_step", "msda_train")):
             if key in res and tkey in traffic_all:           # (same source and caveats as roofline.traffic)
                 res[key]["traffic"], res[key]["traffic_source"] = traffic_all[tkey], traffic_src
+        if "roofline_msda_bwd" in res and isinstance(res["roofline_msda_bwd"].get("deterministic"), dict) and "msda_bwd_deterministic" in traffic_all:
+            res["roofline_msda_bwd"]["deterministic"]["traffic"] = traffic_all["msda_bwd_deterministic"]
         if "roofline_warp" in res and "warp_fwd_nchw" in traffic_all:
             res["roofline_warp"]["nchw_to_nchw"]["traffic"] = traffic_all["warp_fwd_nchw"]
         clock.mark("other_kernel_rooflines")
+    # memory-side bytes over algorithmic bytes, next to every `traffic` (how much of what moved was re-fetched or written twice)
+    def add_ratio(e):
+        if isinstance(e, dict):
+            if e.get("traffic") and e.get("algorithmic_bytes_per_launch"):
+                e["traffic_ratio"] = round(e["traffic"] / e["algorithmic_bytes_per_launch"], 2)
+            for v in e.values():
+                add_ratio(v)
+    for k, e in res.items():
+        if k.startswith("roofline"):
+            add_ratio(e)
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(model, imgs[:1].cpu(), model.frame_proj_mats(M[:1]), a.cpu_budget_s)
         clock.mark("cpu_baseline")

@@ -132,12 +132,15 @@ static int backward_entry(void *stream, const T *grad_col, const T *value, const
         static const bool tile_ok = [] { const char *e = getenv("MVDETR_MSDA_BWD_IMPL"); return !(e && !strcmp(e, "atomic")); }();
         const bool all16 = a16 && aligned(loc, 16) && aligned(aw, 16) && aligned(grad_value, 16) && aligned(grad_loc, 16) &&
                            aligned(grad_aw, 16);
-        // MVDETR_MSDA_BWD_IMPL = split (default: grad_value from msda_bwd_onepass<DOTS = 0>, the sampling gradients from
-        // msda_bwd_sampling_*) | onepass (all three gradients from ONE kernel, msda_backward_onepass.hip) | twopass (rounds 2-4:
-        // msda_bwd_value_tok + msda_bwd_sampling_*) | atomic (the generic kernel)
+        // MVDETR_MSDA_BWD_IMPL = twopass (default of this entry: msda_locality_probe + msda_bwd_value_tok + msda_bwd_sampling_*) |
+        // split (grad_value from msda_bwd_onepass<DOTS = 0>, no probe launch; the default of the FUSED entry below) | onepass (all
+        // three gradients from ONE kernel, msda_backward_onepass.hip) | atomic (the generic kernel).
+        // The default is the measured one (profiles/r06_bwd_ab.txt, same box, realistic / uniform input): Wildtrack 625 / 3,383 us
+        // twopass, 642 / 3,607 split, 671 / 3,960 onepass; MultiviewX 458 / 2,316, 458 / 2,360, 506 / 2,527 -- round 5 had made
+        // `split` the default to save the 6-us probe launch; it moves 2.4 x the bytes and is not faster.
         static const int impl = [] {
             const char *e = getenv("MVDETR_MSDA_BWD_IMPL");
-            return !e ? 0 : !strcmp(e, "onepass") ? 1 : !strcmp(e, "twopass") ? 2 : 0;
+            return !e ? 2 : !strcmp(e, "onepass") ? 1 : !strcmp(e, "split") ? 0 : 2;
         }();
         const bool tile_shapes = tile_ok && msda_tile_supported(B, S, M, D, L, Lq, P, all16, 0, L);
         const bool op_ok = tile_shapes && msda_backward_onepass_supported(B, S, M, D, L, (int64_t)M * L * P * 2);
@@ -257,6 +260,9 @@ int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const
         (ref_batch_stride & 1))
         return (int)hipErrorNotSupported;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // MVDETR_MSDA_BWD_IMPL for this entry: split (default: msda_bwd_onepass<fused, DOTS = 0> + msda_bwd_fused_sampling) | twopass
+    // (msda_bwd_value_tok<fused> for grad_value) | onepass.  Measured (profiles/r06_bwd_ab.txt): Wildtrack 549 us split, 564
+    // twopass, 706 onepass; MultiviewX 386 / 404 / 493.
     static const int impl = [] {
         const char *e = getenv("MVDETR_MSDA_BWD_IMPL");
         return !e ? 0 : !strcmp(e, "onepass") ? 1 : !strcmp(e, "twopass") ? 2 : 0;

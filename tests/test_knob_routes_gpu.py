@@ -6,7 +6,7 @@ oracle (oracle/oracle.c) -- the kernels a knob selects ship in the library and a
 the reference's own strategy for its backward variants: ops/test.py:63-86 runs gradcheck over every channel count, i.e.
 over every one of the col2im kernels cuh:956-1327 dispatches to.
 
-Routes (knob table): MVDETR_MSDA_BWD_IMPL = split (default) | twopass | onepass | atomic,
+Routes (knob table): MVDETR_MSDA_BWD_IMPL = twopass (default) | split | onepass | atomic,
 MVDETR_MSDA_BWD_ORDER = spread, MVDETR_MSDA_GROUP = 0, MVDETR_MSDA_FWD_IMPL = gather | tile, MVDETR_WARP_FWD_NCHW = gather.
 (MVDETR_MSDA_WINDOW_SHIFT = 0 and the MVDETR_WARP_BWD_* knobs have their tests in test_msda_gpu.py / test_warp_gpu.py.)
 """
@@ -21,8 +21,9 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
-BWD_ROUTES = [{}, {"MVDETR_MSDA_BWD_IMPL": "twopass"}, {"MVDETR_MSDA_BWD_IMPL": "onepass"}, {"MVDETR_MSDA_BWD_IMPL": "atomic"},
-              {"MVDETR_MSDA_BWD_ORDER": "spread"}, {"MVDETR_MSDA_BWD_IMPL": "onepass", "MVDETR_MSDA_BWD_ORDER": "spread"}]
+BWD_ROUTES = [{}, {"MVDETR_MSDA_BWD_IMPL": "split"}, {"MVDETR_MSDA_BWD_IMPL": "twopass"}, {"MVDETR_MSDA_BWD_IMPL": "onepass"},
+              {"MVDETR_MSDA_BWD_IMPL": "atomic"}, {"MVDETR_MSDA_BWD_IMPL": "split", "MVDETR_MSDA_BWD_ORDER": "spread"},
+              {"MVDETR_MSDA_BWD_IMPL": "onepass", "MVDETR_MSDA_BWD_ORDER": "spread"}]
 FWD_ROUTES = [{}, {"MVDETR_MSDA_GROUP": "0"}, {"MVDETR_MSDA_FWD_IMPL": "gather"}, {"MVDETR_MSDA_FWD_IMPL": "tile"}]
 
 

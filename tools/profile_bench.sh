@@ -38,8 +38,9 @@ out = {}
 # bench.py key -> the kernels of one call (per-launch averages are summed: a call launches each of them once)
 groups = {"msda_fwd": ["msda_fwd_group"], "warp_fwd": ["warp_fwd_cl<"], "warp_fwd_nchw": ["warp_fwd_nchw_patch"],
           "warp_bwd": ["warp_bwd_scans", "warp_bwd_gather"],
-          # (the grad_value-only instantiations: OnePassCfg<4, 16, 6, 0, ..>; the deterministic launch is OnePassCfg<.., 1, 8>, .., true>)
-          "msda_bwd": ["msda_bwd_onepass<0, mvdetr::OnePassCfg<4, 16, 6, 0", "msda_bwd_sampling"],
+          # (public contract, round 6's default: probe + value_tok + sampling; the grad_value-only one-pass instantiations are
+          # OnePassCfg<4, 16, 6, 0, ..>, the deterministic launch is OnePassCfg<.., 1, 8>, .., true>)
+          "msda_bwd": ["msda_locality_probe", "msda_bwd_value_tok<16, 0>", "msda_bwd_sampling"],
           "msda_bwd_deterministic": ["msda_det_absmax", "msda_bwd_onepass<0, mvdetr::OnePassCfg<4, 16, 6, 1", "msda_det_finish"],
           "msda_train": ["msda_fwd_group2<%7, 2, 2>", "msda_bwd_onepass<1, mvdetr::OnePassCfg<4, 16, 6, 0", "msda_bwd_fused_sampling"]}
 for key, kerns in groups.items():
@@ -55,8 +56,10 @@ for key, kerns in groups.items():
         out[key + "_kernels"] = kerns
 out["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over: python bench.py $ARGS (msda_fwd: the same with "
                "--headline-only, i.e. only the launches roofline.avg_launch_us averages); "
-               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane "
-               "reads (MI355X_MICROARCH.md, HBM section; re-checked here on a device copy of known size), WRITE_SIZE is exact. "
+               "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE tallies every 128-byte line request at 64 bytes "
+               "(MI355X_MICROARCH.md, HBM section) -- calibrated in round 6 on 1 GiB device copies with 4, 8 and 16 bytes per lane and on "
+               "sparse 8-byte reads (tools/copy_calibration.py, profiles/r06_copy_calibration.txt): the factor is 2 for every width; "
+               "WRITE_SIZE is exact for whole lines and counts 32 bytes per 16-byte partial write. "
                "Infinity-Cache hits are included, so this is an upper bound on HBM bytes.")
 json.dump(out, open("$O/${TAG}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
