@@ -130,6 +130,26 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// A value computed once per DEVICE (the grid size of a persistent kernel: CU count x workgroups per CU, and the one-time
+// hipFuncSetAttribute for its dynamic LDS, which is per device as well).  A function-local `static int` made the first caller's
+// device decide for every later one -- a process that drives several GPUs (DataParallel, one thread per device) launched the wrong
+// grid on the others, and the deterministic backward's job partition depends on the grid.  Lock-free: a race computes the value twice.
+template <typename T> struct PerDevice {
+    static constexpr int MAX_DEVICES = 64;
+    T value[MAX_DEVICES];
+    bool ready[MAX_DEVICES];
+    template <typename F> T get(F compute)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return compute();
+        if (!__atomic_load_n(&ready[dev], __ATOMIC_ACQUIRE)) {
+            value[dev] = compute();
+            __atomic_store_n(&ready[dev], true, __ATOMIC_RELEASE);
+        }
+        return value[dev];
+    }
+};
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 inline bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

@@ -429,7 +429,8 @@ static int launch_bwd_fused_sampling(hipStream_t st, const float *go, const floa
     constexpr int DEPTH = 2;
     constexpr int LDS = Group2Lds<Cfg, NG>::BYTES;
     auto kernel = &msda_bwd_fused_sampling<Cfg, NG, DEPTH>;
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_fused_sampling<Cfg, NG, DEPTH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
@@ -439,7 +440,7 @@ static int launch_bwd_fused_sampling(hipStream_t st, const float *go, const floa
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_fused_sampling<Cfg, NG, DEPTH>, Cfg::THREADS, LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
-    }();
+    });
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, go, value, shapes, lsi, raw, raw_q, ref,
                        ref_bstride, stats, out_fwd, B, S, M, grad_raw, opts);
     return (int)hipGetLastError();

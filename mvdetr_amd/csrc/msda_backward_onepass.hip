@@ -164,6 +164,16 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
         // (the fused entry's callers promise equal level shapes, and the deterministic mode has no other kernel: make the misuse loud)
         for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < (int64_t)B * S * M * D; i += (int64_t)gridDim.x * THREADS)
             grad_value[i] = __builtin_nanf("");
+        // ... in every gradient this launch owes: the raw tensor's (fused, when this kernel forms it), or grad_sampling_loc /
+        // grad_attn_weight (deterministic mode of the public contract)
+        if (FUSED && DOTS && grad_loc)
+            for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < (int64_t)B * S * raw_q; i += (int64_t)gridDim.x * THREADS)
+                grad_loc[i] = __builtin_nanf("");
+        if (!FUSED && DOTS && grad_loc && grad_aw)
+            for (int64_t i = (int64_t)blockIdx.x * THREADS + tid; i < (int64_t)B * S * M * L * P; i += (int64_t)gridDim.x * THREADS) {
+                grad_loc[2 * i] = grad_loc[2 * i + 1] = __builtin_nanf("");
+                grad_aw[i] = __builtin_nanf("");
+            }
         return;
     }
     if (!equal) {
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
     const float iw = 1.f / fW, ih = 1.f / fH;
     constexpr int HPS = 32 / D;
     // sampling data of (query q, head, level l): normalised locations (x, y) x 4 points in la / lb, weights in wa
-    auto fetch = [&](int64_t q, int b, int head, int l, float4 &la, float4 &lb, float4 &wa) {
+    // (FUSED, rr given: la / lb stay the raw offsets in pixels and *rr is the reference point -- the bound pass forms the
+    // position from them exactly as pass 1 does, fused_px: ONE expression for every pass)
+    auto fetch = [&](int64_t q, int b, int head, int l, float4 &la, float4 &lb, float4 &wa, float2 *rr = nullptr) {
         if constexpr (FUSED) {
             const float *rp = loc + q * raw_q + (l * (M / HPS) + head / HPS) * (HPS * P * 3);
             const float4 oa = *reinterpret_cast<const float4 *>(rp + (head % HPS) * P * 2);
@@ -193,8 +205,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
             const float4 lg = *reinterpret_cast<const float4 *>(rp + HPS * P * 2 + (head % HPS) * P);
             const float2 r = *reinterpret_cast<const float2 *>(ref + b * ref_bstride + ((int64_t)l * S + (q - (int64_t)b * S)) * 2);
             const float2 st = *reinterpret_cast<const float2 *>(aw + (q * M + head) * 2);
-            la = make_float4(__fmaf_rn(oa.x, iw, r.x), __fmaf_rn(oa.y, ih, r.y), __fmaf_rn(oa.z, iw, r.x), __fmaf_rn(oa.w, ih, r.y));
-            lb = make_float4(__fmaf_rn(ob.x, iw, r.x), __fmaf_rn(ob.y, ih, r.y), __fmaf_rn(ob.z, iw, r.x), __fmaf_rn(ob.w, ih, r.y));
+            if (rr) {
+                la = oa;
+                lb = ob;
+                *rr = r;
+            } else {
+                la = make_float4(__fmaf_rn(oa.x, iw, r.x), __fmaf_rn(oa.y, ih, r.y), __fmaf_rn(oa.z, iw, r.x), __fmaf_rn(oa.w, ih, r.y));
+                lb = make_float4(__fmaf_rn(ob.x, iw, r.x), __fmaf_rn(ob.y, ih, r.y), __fmaf_rn(ob.z, iw, r.x), __fmaf_rn(ob.w, ih, r.y));
+            }
             wa = make_float4(__expf(lg.x - st.x) * st.y, __expf(lg.y - st.x) * st.y, __expf(lg.z - st.x) * st.y, __expf(lg.w - st.x) * st.y);
         } else {
             const float *lp = loc + ((q * M + head) * L + l) * P * 2;
@@ -400,6 +418,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                     // lanes = (cell, camera) items of a pass of 8 cameras: the item's sampling data (kept for the mass pass) and
                     // its grad_out row of this head
                     float4 la8[IPT], lb8[IPT], wa8[IPT];
+                    [[maybe_unused]] float2 rf8[IPT];        // (FUSED) the items' reference points
                     bool act8[IPT];
                     auto load8 = [&](int c0, float &gm) {
 #pragma unroll
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                             const int qy = Y0 + ci / TW, qx = X0 + ci % TW;
                             act8[k] = it < CELLS * CAMS && c < L && qy < Hq && qx < Wq;
                             const int64_t q = (int64_t)b * S + lsi[act8[k] ? c : 0] + (act8[k] ? (int64_t)qy * Wq + qx : 0);
-                            fetch(q, b, head, l, la8[k], lb8[k], wa8[k]);
+                            fetch(q, b, head, l, la8[k], lb8[k], wa8[k], &rf8[k]);
                             const float *gp = go + q * row + ch0;
                             float m = 0.f;
 #pragma unroll
@@ -449,14 +468,24 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                             if (L > CAMS) load8(c0, unused_g);
 #pragma unroll
                             for (int k = 0; k < IPT; ++k) {
-                                const float xs[4] = {op_pix(la8[k].x, fW), op_pix(la8[k].z, fW), op_pix(lb8[k].x, fW), op_pix(lb8[k].z, fW)};
-                                const float ys[4] = {op_pix(la8[k].y, fH), op_pix(la8[k].w, fH), op_pix(lb8[k].y, fH), op_pix(lb8[k].w, fH)};
+                                const float lxs[4] = {la8[k].x, la8[k].z, lb8[k].x, lb8[k].z}, lys[4] = {la8[k].y, la8[k].w, lb8[k].y, lb8[k].w};
                                 const float as[4] = {wa8[k].x, wa8[k].y, wa8[k].z, wa8[k].w};
 #pragma unroll
                                 for (int p = 0; p < P; ++p) {
-                                    const float x = xs[p], y = ys[p];
+                                    // (pass 1's expressions, tap_of: a tap is inside the window, and on a token, in every pass or in none)
+                                    float x, y, fx, fy;
+                                    if constexpr (FUSED) {
+                                        float wx_, wy_;
+                                        fused_px(rf8[k].x, lxs[p], fW, x, fx, wx_);
+                                        fused_px(rf8[k].y, lys[p], fH, y, fy, wy_);
+                                    } else {
+                                        x = op_pix(lxs[p], fW);
+                                        y = op_pix(lys[p], fH);
+                                        fx = floorf(x);
+                                        fy = floorf(y);
+                                    }
                                     if (act8[k] && in_window(x, y)) {
-                                        const int tok = ((int)floorf(y) - oy) * WWP + ((int)floorf(x) - ox);
+                                        const int tok = ((int)fy - oy) * WWP + ((int)fx - ox);
                                         __hip_atomic_fetch_add(mass + tok, __float2int_ru(fabsf(as[p]) * wscale), __ATOMIC_RELAXED,
                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
                                     }
@@ -873,7 +902,8 @@ static int launch_onepass_nc(hipStream_t st, const float *go, const float *value
                           long long *det_acc, const unsigned *det_hdr)
 {
     constexpr int LDS = Cfg::LDS;
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_onepass<FUSED, Cfg, NC, DET>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
@@ -887,7 +917,7 @@ static int launch_onepass_nc(hipStream_t st, const float *go, const float *value
             fprintf(stderr, "msda_bwd_onepass<%d, %dx%d, %d, %d>: %d workgroups per CU (LDS admits %d), %d B of LDS, %d threads\n", FUSED,
                     Cfg::TH, Cfg::TW, NC, (int)DET, per_cu, Cfg::WGS, LDS, Cfg::THREADS);
         return (cus * per_cu + 7) / 8 * 8;
-    }();
+    });
     hipLaunchKernelGGL((msda_bwd_onepass<FUSED, Cfg, NC, DET>), dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, go, value, shapes, lsi, loc, aw,
                        B, S, M, L, grad_value, grad_loc, grad_aw, ref, ref_bstride, raw_q, out_fwd, opts, det_acc, det_hdr);
     return (int)hipGetLastError();

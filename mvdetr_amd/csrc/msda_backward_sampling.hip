@@ -632,7 +632,8 @@ static int launch_sampling_groups(hipStream_t st, const float *go, const float *
                                   int64_t ref_bstride = 0, int raw_q = 0, const float *out_fwd = nullptr)
 {
     constexpr int LDS = LG * RS_NTOK * D * 4;
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_groups<D, LG, WPE, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256;
@@ -640,7 +641,7 @@ static int launch_sampling_groups(hipStream_t st, const float *go, const float *
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
         return (cus * (WPE / 2) + 7) / 8 * 8;                 // WPE / 2 workgroups of 8 waves per CU
-    }();
+    });
     hipLaunchKernelGGL((msda_bwd_sampling_groups<D, LG, WPE, FUSED>), dim3((unsigned)blocks), dim3(RS_THREADS), LDS, st, go, value, shapes,
                        lsi, loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits, ref, ref_bstride, raw_q, out_fwd);
     return (int)hipGetLastError();
@@ -651,7 +652,8 @@ static int launch_sampling_resident(hipStream_t st, const float *go, const float
                                     float *grad_loc, float *grad_aw, const int *local_hits)
 {
     const int lds = L * RS_NTOK * RS_D * 4;
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_sampling_resident),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, RS_MAXL * RS_NTOK * RS_D * 4);
         int dev = 0, cus = 256;
@@ -659,7 +661,7 @@ static int launch_sampling_resident(hipStream_t st, const float *go, const float
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             cus = 256;
         return (cus + 7) / 8 * 8;                             // one workgroup per CU (LDS)
-    }();
+    });
     hipLaunchKernelGGL(msda_bwd_sampling_resident, dim3((unsigned)blocks), dim3(RS_THREADS), lds, st, go, value, shapes, lsi,
                        loc, aw, B, S, M, L, grad_loc, grad_aw, local_hits);
     return (int)hipGetLastError();

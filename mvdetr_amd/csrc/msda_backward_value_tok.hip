@@ -539,7 +539,8 @@ int launch_value_tok(hipStream_t st, const float *go, const float *value, const 
                      int64_t ref_bstride, int raw_q)
 {
     constexpr int LDS = 16 * 44 * 64 + 4 * 2 * 4 * 34 * 8;
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_bwd_value_tok<D, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
@@ -549,7 +550,7 @@ int launch_value_tok(hipStream_t st, const float *go, const float *value, const 
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_value_tok<D, FUSED>, 256, LDS) != hipSuccess || per_cu < 1)
             per_cu = 3;
         return (cus * per_cu + 7) / 8 * 8;
-    }();
+    });
     hipLaunchKernelGGL((msda_bwd_value_tok<D, FUSED>), dim3((unsigned)blocks), dim3(256), LDS, st, go, value, shapes, lsi, loc, aw,
                        B, S, M, L, grad_value, grad_loc, grad_aw, local_hits, ref, ref_bstride, raw_q);
     return (int)hipGetLastError();

@@ -99,7 +99,8 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
                        const float *loc, const float *aw, const float *ref, int64_t ref_bstride, SamplingLayout lay,
                        QueryLevels qr, int B, int S, int M, int L, float *out, const int *local_hits)
 {
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         int dev = 0, cus = 256, per_cu = 0;
@@ -111,7 +112,7 @@ static int launch_tile(hipStream_t st, const float *value, const int64_t *shapes
             per_cu = 2;
         int n = cus * per_cu;
         return (n + 7) / 8 * 8;                          // keep the XCD interleave whole
-    }();
+    });
     static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_tile<Cfg, FUSED>));
     msda_note_forward_kernel("msda_fwd_tile", &res);
     hipLaunchKernelGGL((msda_fwd_tile<Cfg, FUSED>), dim3((unsigned)blocks), dim3(Cfg::THREADS), Cfg::LDS_BYTES,

@@ -610,7 +610,8 @@ static int launch_group2(hipStream_t st, const float *value, const int64_t *shap
     constexpr int FB = TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
     constexpr int LDS = Group2Lds<Cfg, NG>::BYTES > FB ? Group2Lds<Cfg, NG>::BYTES : FB;
     auto kernel = &msda_fwd_group2<Cfg, NG, FUSED, DEPTH>;
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group2<Cfg, NG, FUSED, DEPTH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
@@ -621,7 +622,7 @@ static int launch_group2(hipStream_t st, const float *value, const int64_t *shap
                                                          LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
-    }();
+    });
     static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_group2<Cfg, NG, FUSED, DEPTH>));
     msda_note_forward_kernel("msda_fwd_group2[pipelined taps, LDS-DMA windows]", &res);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts, stats);

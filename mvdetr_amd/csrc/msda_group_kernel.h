@@ -488,7 +488,8 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
     constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
                                                                                    : TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES;
     auto kernel = &msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>;
-    static int blocks = [] {
+    static PerDevice<int> blocks_of;
+    const int blocks = blocks_of.get([] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         int dev = 0, cus = 256, per_cu = 0;
@@ -499,7 +500,7 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
                                                          LDS) != hipSuccess || per_cu < 1)
             per_cu = 2;
         return (cus * per_cu + 7) / 8 * 8;
-    }();
+    });
     static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>));
     msda_note_forward_kernel(DMA ? (SPLIT > 1 ? "msda_fwd_group[camera-split, LDS-DMA windows]" : "msda_fwd_group[LDS-DMA windows]")
                                  : (SPLIT > 1 ? "msda_fwd_group[camera-split]" : "msda_fwd_group"), &res);

@@ -325,6 +325,24 @@ def set_backward_deterministic(on: bool) -> bool:
     return bool(_lib.lib().mvdetr_msda_set_backward_deterministic(1 if on else 0))
 
 
+def backward_deterministic() -> bool:
+    """Whether the bit-reproducible backward is on (the library holds the state; MVDETR_MSDA_BWD_DETERMINISTIC=1 sets its
+    initial value)."""
+    lib = _lib.lib()
+    prev = lib.mvdetr_msda_set_backward_deterministic(1)
+    if not prev:
+        lib.mvdetr_msda_set_backward_deterministic(0)
+    return bool(prev)
+
+
+def backward_deterministic_supported(B: int, S: int, M: int, D: int, L: int, Lq: int, P: int) -> bool:
+    """The calls the deterministic mode serves (csrc/msda_backward_onepass.hip: msda_backward_deterministic_supported): fp32
+    deformable-encoder calls with 16-channel heads and 4 points, at most 16 levels, one batch element's tensors below 2 GiB and
+    S * L * P < 2^24 (the 64-bit sums' headroom).  Everything else is refused with hipErrorNotSupported while the mode is on."""
+    return (D == 16 and P == 4 and Lq == S and 1 <= L <= 16 and S * M * D * 4 < 2 ** 31 and S * M * L * P * 2 * 4 < 2 ** 31
+            and S * L * P < 2 ** 24)
+
+
 def release_scratch() -> None:
     """Hand back the deterministic mode's cached accumulators (``mvdetr_msda_release_scratch``); call it when no backward is
     in flight."""

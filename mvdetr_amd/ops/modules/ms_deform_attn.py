@@ -202,6 +202,12 @@ class MSDeformAttn(nn.Module):
             self._check_query_levels(input_spatial_shapes, query_levels, Len_q)
         needs_grad = torch.is_grad_enabled() and (query.requires_grad or (value is not None and value.requires_grad)
                                                   or any(p.requires_grad for p in self.parameters()))
+        if needs_grad and query.is_cuda and MSDA.backward_deterministic() and not (
+                query.dtype == torch.float32 and MSDA.backward_deterministic_supported(N, Len_in, M, D, self.n_levels, Len_q, self.n_points)):
+            # (the library would refuse at BACKWARD time with hipErrorNotSupported -- after the whole forward: say it here)
+            raise RuntimeError("MSDeformAttn: the deterministic backward (MSDA.set_backward_deterministic / MVDETR_MSDA_BWD_DETERMINISTIC) "
+                               f"serves fp32 deformable-encoder calls with 16-channel heads only; this call has d_model / n_heads = {D}, "
+                               f"{self.n_levels} levels, Len_q = {Len_q}, Len_in = {Len_in}, dtype {query.dtype}")
         if (self.fused_inference and reference_points.shape[-1] == 2 and reference_points.dim() == 5
                 and not needs_grad and query.is_cuda and query.dtype == torch.float32 and D in (16, 32)
                 and (value is None or (value.is_cuda and value.dtype == torch.float32))

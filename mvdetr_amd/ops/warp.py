@@ -96,10 +96,13 @@ class _BackwardPlans:
     own ``KEEP`` most recent plans (a DataParallel run's replicas do not evict each other), and the library's geometry knobs
     (``MVDETR_WARP_BWD_GEOMETRY`` / ``MVDETR_WARP_BWD_HEAVY``, which change a plan's contents) are part of the key."""
     KEEP = 4
+    MAX_PARTS = 8                  # (device, stream) partitions kept, least recently used first out: short-lived side streams
+                                   # (and recycled stream handles) must not pin plans and matrices for the life of the process
 
     def __init__(self):
         self.lock = threading.Lock()
-        self.parts = {}            # (device index, stream pointer) -> [(M, version, key, plan), ...], most recent first
+        self.parts = {}            # (device index, stream pointer) -> [(M, version, key, plan), ...], most recent first;
+                                   # the dict itself is kept in order of last use (oldest partition first)
 
     def get(self, M, shapes):
         n, c, h, w, H, W = shapes
@@ -107,7 +110,8 @@ class _BackwardPlans:
         part_key = (M.device.index, int(stream or 0))
         key = (shapes, os.environ.get("MVDETR_WARP_BWD_GEOMETRY"), os.environ.get("MVDETR_WARP_BWD_HEAVY"))
         with self.lock:
-            entries = self.parts.setdefault(part_key, [])
+            entries = self.parts.pop(part_key, [])
+            self.parts[part_key] = entries                  # (most recently used partition last)
             for i, (m, ver, k, plan) in enumerate(entries):
                 if k == key and m.data_ptr() == M.data_ptr() and ver == M._version and m.dtype == M.dtype:
                     if i:
@@ -124,9 +128,12 @@ class _BackwardPlans:
             return None
         _lib.check(rc, "warp_backward_plan")
         with self.lock:
-            entries = self.parts.setdefault(part_key, [])
+            entries = self.parts.pop(part_key, [])
+            self.parts[part_key] = entries
             entries.insert(0, (M, M._version, key, plan))
             del entries[self.KEEP:]
+            while len(self.parts) > self.MAX_PARTS:
+                del self.parts[next(iter(self.parts))]
         return plan
 
     def clear(self):

@@ -7,7 +7,7 @@ workgroups are scheduled, while staying within the parity bars of the default pa
 import pytest
 import torch
 
-from helpers import encoder_msda_inputs, random_msda_inputs
+from helpers import encoder_msda_inputs, level_start_index, random_msda_inputs
 from oracle import c_oracle
 
 pytestmark = pytest.mark.gpu
@@ -170,6 +170,32 @@ def test_deterministic_mode_refuses_what_it_cannot_serve(deterministic):
     MSDA.set_backward_deterministic(False)
     gv = MSDA.ms_deform_attn_backward(*dev(value, shapes, lsi, loc, aw, go), 64)[0]
     assert torch.isfinite(gv).all()
+
+
+def test_module_refuses_early_what_the_deterministic_mode_cannot_serve(deterministic):
+    """a model with 32-channel heads used to run its whole forward and fail at backward time with error 801.  The
+    module says so at the first forward that needs gradients; inference is not affected, and 16-channel heads train."""
+    MSDA = deterministic
+    assert MSDA.backward_deterministic()
+    from mvdetr_amd.ops.modules import MSDeformAttn
+    L, H, W = 3, 8, 12
+    shapes = torch.tensor([[H, W]] * L)
+    S = L * H * W
+    ys, xs = torch.meshgrid(torch.arange(H) + 0.5, torch.arange(W) + 0.5, indexing="ij")
+    ref = torch.stack([xs / W, ys / H], -1).reshape(-1, 1, 1, 2).repeat(L, L, 4, 1)[None].cuda()
+    for d_model, ok in ((128, True), (256, False)):                  # 8 heads: 16- / 32-channel heads
+        mod = MSDeformAttn(d_model, L, 8, 4).cuda()
+        q = torch.randn(1, S, d_model, device="cuda")
+        with torch.no_grad():
+            mod(q, ref, q, shapes.cuda(), level_start_index(shapes).cuda())           # inference: always served
+        if ok:
+            mod(q, ref, q, shapes.cuda(), level_start_index(shapes).cuda()).sum().backward()
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mod.parameters())
+        else:
+            with pytest.raises(RuntimeError, match="deterministic backward"):
+                mod(q, ref, q, shapes.cuda(), level_start_index(shapes).cuda())
+    MSDA.set_backward_deterministic(False)
+    assert not MSDA.backward_deterministic()
 
 
 def test_deterministic_fused_training_pair(deterministic):
