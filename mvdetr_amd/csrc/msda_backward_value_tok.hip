@@ -57,8 +57,14 @@ __device__ __forceinline__ float pix(float loc, float size) { return __fmaf_rn(l
 
 }  // namespace
 
+#ifndef MVDETR_VT_WGS
+#define MVDETR_VT_WGS 3      // workgroups per CU (register budget 512 / this per lane)
+#endif
+#ifndef MVDETR_VT_RB
+#define MVDETR_VT_RB 2       // 16-byte entry reads (2 taps each) per batch of the accumulation stream
+#endif
 template <int D, int FUSED>
-__global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
+__global__ __launch_bounds__(256, MVDETR_VT_WGS) void msda_bwd_value_tok(
     const float *__restrict__ go, const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc, const float *__restrict__ aw, int B, int S, int M,
     int L, float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_aw,
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(256, 3) void msda_bwd_value_tok(
                 if (!direct_only) {
                     // (2 x 16 bytes = 4 taps per batch: 4, 8 and 16 were measured too -- 8 and 16 spill inside the loop and lose 6 %,
                     // 4 leaves 16 - 44 bytes of scratch per lane and is 1 - 2 % slower than 2, which has none)
-                    constexpr int RB = 2, NB = CAMS * P / 2 / RB;             // float4 (= 2 taps) per batch, batches per step
+                    constexpr int RB = MVDETR_VT_RB, NB = CAMS * P / 2 / RB;             // float4 (= 2 taps) per batch, batches per step
                     float4 nx[RB];
                     auto read_batch = [&](int bt) {
 #pragma unroll
@@ -549,6 +555,7 @@ int launch_value_tok(hipStream_t st, const float *go, const float *value, const 
             cus = 256;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msda_bwd_value_tok<D, FUSED>, 256, LDS) != hipSuccess || per_cu < 1)
             per_cu = 3;
+        if (per_cu > MVDETR_VT_WGS) per_cu = MVDETR_VT_WGS;
         return (cus * per_cu + 7) / 8 * 8;
     });
     hipLaunchKernelGGL((msda_bwd_value_tok<D, FUSED>), dim3((unsigned)blocks), dim3(256), LDS, st, go, value, shapes, lsi, loc, aw,
