@@ -426,7 +426,10 @@ static int launch_bwd_fused_sampling(hipStream_t st, const float *go, const floa
                                      const int64_t *lsi, const float *raw, int raw_q, const float *ref, int64_t ref_bstride,
                                      const float *stats, const float *out_fwd, int B, int S, int M, float *grad_raw, int opts)
 {
-    constexpr int DEPTH = 2;
+#ifndef MVDETR_FS_DEPTH
+#define MVDETR_FS_DEPTH 2
+#endif
+    constexpr int DEPTH = MVDETR_FS_DEPTH;
     constexpr int LDS = Group2Lds<Cfg, NG>::BYTES;
     auto kernel = &msda_bwd_fused_sampling<Cfg, NG, DEPTH>;
     static PerDevice<int> blocks_of;
