@@ -52,9 +52,8 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
     const int opts = group_opts(fused) | ((standdown && !fused) ? GROUP_OPT_STANDDOWN : 0);
 #define GROUP_ARGS st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts
     if (L >= 9 && L <= 16) {           // many cameras: 4 lane groups x up to 4 cameras (msda_forward_group_many.hip)
-        if (stats) return (int)hipErrorNotSupported;
         return msda_forward_group_many(st, value, shapes, lsi, off, logit, ref, ref_bstride, fused, lay, B, S, M, D, L, out,
-                                       local_hits, opts);
+                                       local_hits, opts, fused ? stats : nullptr);
     }
     // 6 / 7 cameras: the software-pipelined kernel (msda_group2_kernel.h) for every entry -- fused (raw offsets / logits, one
     // or P reference points per (query, level)) and the public contract (final locations / weights)

@@ -190,9 +190,9 @@ int msda_forward_tile_fused(hipStream_t st, const float *value, const int64_t *s
     // window to amortise the grouped staging and runs the tile kernel.
     const bool all_levels = ql0 == 0 && ql1 == L;
     const bool grouped = all_levels && msda_group_supported(D, L) && msda_group_fits(B, S, M * D, lay);
-    // the training entry's statistics: msda_fwd_group2 (6 / 7 levels) writes them itself; every other route runs as it does for
-    // inference and a small pass over the logits follows
-    const bool own_stats = grouped && L <= 7;
+    // the training entry's statistics: the camera-grouped kernels (6 / 7 levels: msda_fwd_group2; 9 - 16: msda_fwd_group) write them
+    // themselves; the tile kernel runs as it does for inference and a small pass over the logits follows
+    const bool own_stats = grouped;
     int rc;
     if (grouped)
         rc = msda_forward_group(st, value, shapes, lsi, offsets, logits, ref, ref_bstride, shared_ref ? 2 : 1, lay, B, S,

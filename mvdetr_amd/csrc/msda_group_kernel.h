@@ -63,7 +63,7 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ off, const float *__restrict__ logit,
     const float *__restrict__ ref, int64_t ref_bstride, SamplingLayout lay, int B, int S, int M,
-    float *__restrict__ out, const int *__restrict__ local_hits, int opts)
+    float *__restrict__ out, const int *__restrict__ local_hits, int opts, float *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) float win[];
     GROUP_STAMP(0);
@@ -97,6 +97,10 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
     };
     if (!levels_equal()) {
         fallback();
+        // (the training entry needs equal level shapes -- its caller checks; statistics this path cannot give are NaN)
+        if (stats)
+            for (int64_t i = (int64_t)blockIdx.x * Cfg::THREADS + threadIdx.x; i < (int64_t)B * S * M * 2; i += (int64_t)gridDim.x * Cfg::THREADS)
+                stats[i] = __builtin_nanf("");
         return;
     }
     const int Hq = (int)shapes[0], Wq = (int)shapes[1];
@@ -456,6 +460,11 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
                     }
                 }
                 const float inv = FUSED ? 1.f / ssum[c] : 1.f;
+                // training (mvdetr_msda_forward_fused_train_f32): the softmax statistics of (query, head) -- the running maximum
+                // the weights were formed against and the reciprocal of their sum -- for the fused backward (round 6: a
+                // separate pass over the logits, msda_softmax_stats, took 0.35 of this kernel's 1.1 ms at 16 cameras)
+                if (FUSED && stats && ch_off == 0)
+                    *reinterpret_cast<float2 *>(stats + ((cq + cell) * M + head) * 2) = make_float2(smax[c], inv);
                 float *o = out + cq * row + (cell * (unsigned)row + (unsigned)(head * D + ch_off));
 #pragma unroll
                 for (int k = 0; k < NV; ++k)
@@ -476,13 +485,16 @@ __global__ __launch_bounds__(Cfg::THREADS, WAVES) void msda_fwd_group(
 using GWide16 = TileCfg<16, 32, 6, 16, 6, 256>;
 using GWide32 = TileCfg<32, 32, 6, 16, 6, 256>;
 // many cameras: 4 lane groups of 3 waves on one window, 4 cameras each -- 768 threads, one workgroup per CU
-using GQuad16 = TileCfg<16, 32, 6, 16, 6, 768>;
-using GQuad32 = TileCfg<32, 32, 6, 16, 6, 768>;
+#ifndef MVDETR_QUAD_TH
+#define MVDETR_QUAD_TH 6
+#endif
+using GQuad16 = TileCfg<16, 32, MVDETR_QUAD_TH, 16, 6, MVDETR_QUAD_TH * 16 * 2 * 4>;
+using GQuad32 = TileCfg<32, 32, MVDETR_QUAD_TH, 16, 6, MVDETR_QUAD_TH * 16 * 2 * 4>;
 
 template <typename Cfg, int NG, int WAVES, int FUSED, int SPLIT = 1, bool DMA = false>
 static int launch_group(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                         const float *off, const float *logit, const float *ref, int64_t ref_bstride,
-                        SamplingLayout lay, int B, int S, int M, float *out, const int *local_hits, int opts)
+                        SamplingLayout lay, int B, int S, int M, float *out, const int *local_hits, int opts, float *stats = nullptr)
 {
     // dynamic LDS: the larger of this kernel's window and the fallback body's
     constexpr int LDS = Cfg::LDS_BYTES > TileCfg<Cfg::D, 32, 8, 16, 6>::LDS_BYTES ? Cfg::LDS_BYTES
@@ -504,7 +516,7 @@ static int launch_group(hipStream_t st, const float *value, const int64_t *shape
     static const KernelResources res = kernel_resources(reinterpret_cast<const void *>(&msda_fwd_group<Cfg, NG, WAVES, FUSED, SPLIT, DMA>));
     msda_note_forward_kernel(DMA ? (SPLIT > 1 ? "msda_fwd_group[camera-split, LDS-DMA windows]" : "msda_fwd_group[LDS-DMA windows]")
                                  : (SPLIT > 1 ? "msda_fwd_group[camera-split]" : "msda_fwd_group"), &res);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(Cfg::THREADS), LDS, st, value, shapes, lsi, off, logit, ref, ref_bstride, lay, B, S, M, out, local_hits, opts, stats);
     return (int)hipGetLastError();
 }
 

@@ -93,7 +93,7 @@ int msda_forward_group(hipStream_t st, const float *value, const int64_t *shapes
 int msda_forward_group_many(hipStream_t st, const float *value, const int64_t *shapes, const int64_t *lsi,
                             const float *off, const float *logit, const float *ref, int64_t ref_bstride, int fused,
                             SamplingLayout lay, int B, int S, int M, int D, int L, float *out, const int *local_hits,
-                            int opts);
+                            int opts, float *stats = nullptr);
 
 // Tile count of one level, recomputed by every workgroup from the device-side shapes (uniform ->
 // scalar registers).

@@ -172,13 +172,15 @@ def test_module_trains_through_the_fused_pair(ops):
         assert params[k].grad.abs().max().item() > 0
 
 
-@pytest.mark.parametrize("name,L,H,W,B", [("wildtrack", 7, 60, 180, 1), ("multiviewx_batch4", 6, 80, 125, 4)])
-def test_fused_training_pair_at_wildtrack_size(ops, name, L, H, W, B):
-    """Full Wildtrack shape (75,600 queries x 8 heads x 7 levels x 4 points) and BASELINE configs[3]'s encoder shape (MultiviewX,
-    6 cameras, 4 frames per step: 240,000 queries): every element of grad_value and of the raw gradient against the fp64 C oracle
-    chained through the module arithmetic."""
+@pytest.mark.parametrize("name,L,H,W,B,D", [("wildtrack", 7, 60, 180, 1, 16), ("multiviewx_batch4", 6, 80, 125, 4, 16),
+                                            ("stress16", 16, 60, 180, 1, 32)])
+def test_fused_training_pair_at_wildtrack_size(ops, name, L, H, W, B, D):
+    """Full Wildtrack shape (75,600 queries x 8 heads x 7 levels x 4 points), BASELINE configs[3]'s encoder shape (MultiviewX,
+    6 cameras, 4 frames per step: 240,000 queries) and configs[4]'s (16 cameras, 32-channel heads: 172,800 queries x 8 heads x 16
+    levels -- the general route: msda_fwd_group<SPLIT> + statistics, msda_bwd_value_tok<32, fused> + the level-groups sampling
+    kernel): every element of grad_value and of the raw gradient against the fp64 C oracle chained through the module arithmetic."""
     MSDA = ops
-    M, D = 8, 16
+    M = 8
     value, shapes, lsi, ref_ql, off, logit = _raw_inputs(L, H, W, M, D, B, seed=0, noise_px=1.0)
     raw, rows = _to_raw(MSDA, off, logit, M, L, D)
     ref_lm = ref_ql.transpose(0, 1).contiguous()[None]
