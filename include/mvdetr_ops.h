@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MVDETR_OPS_ABI_VERSION 13   /* 12: + mvdetr_warp_perspective_backward_tagged_*; 13: + mvdetr_msda_set_backward_deterministic; the fused training pair takes every encoder shape */
+#define MVDETR_OPS_ABI_VERSION 14   /* 12: + mvdetr_warp_perspective_backward_tagged_*; 13: + mvdetr_msda_set_backward_deterministic; the fused training pair takes every encoder shape; 14: + mvdetr_msda_get_backward_deterministic */
 
 /* ABI version of the loaded library (checked by the Python loader). */
 int mvdetr_ops_abi_version(void);
@@ -305,6 +305,9 @@ int mvdetr_msda_set_forward_impl(int impl);
  * unequal level shapes (device data) fill grad_value with NaN.  Returns the previous state; the initial state comes from
  * MVDETR_MSDA_BWD_DETERMINISTIC=1. */
 int mvdetr_msda_set_backward_deterministic(int on);
+/* The mode's current state (1 = on), without changing it (ABI 14: a caller that only wants to KNOW -- MSDeformAttn.forward
+ * refusing a training call the mode cannot serve -- must not toggle a process-wide switch other threads' backwards read). */
+int mvdetr_msda_get_backward_deterministic(void);
 
 /* The deterministic mode keeps its 64-bit accumulators (8 bytes per value element) per (device, stream) between calls
  * (hipMallocAsync on the call's stream, grown on demand).  This drops every cached buffer; call it when no backward is in flight.

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 # MVDETR_OPS_LIB: another build of the same sources (the phase-stamp build libmvdetr_ops_trace.so of tools/experiments)
 LIB_PATH = os.environ.get("MVDETR_OPS_LIB") or os.path.join(CSRC, "libmvdetr_ops.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 _MSDA_FWD = [_vp] * 6 + [_i] * 7 + [_vp]
@@ -36,6 +36,7 @@ SIGNATURES = {
     "mvdetr_msda_last_forward_resources": ([ctypes.POINTER(ctypes.c_int)] * 3, _i),
     "mvdetr_msda_set_forward_impl": ([_i], _i),
     "mvdetr_msda_set_backward_deterministic": ([_i], _i),
+    "mvdetr_msda_get_backward_deterministic": ([], _i),
     "mvdetr_msda_release_scratch": ([], _i),
     "mvdetr_warp_last_kernel": ([], ctypes.c_char_p),
     "mvdetr_warp_release_scratch": ([], _i),

@@ -231,6 +231,8 @@ int mvdetr_msda_set_backward_deterministic(int on)
     return mvdetr::backward_deterministic().exchange(on ? 1 : 0);
 }
 
+int mvdetr_msda_get_backward_deterministic(void) { return mvdetr::backward_deterministic().load(std::memory_order_relaxed); }
+
 int mvdetr_msda_release_scratch(void) { return mvdetr::msda_release_det_scratch(); }
 
 int mvdetr_msda_backward_fused_f32(void *stream, const float *grad_output, const float *value,

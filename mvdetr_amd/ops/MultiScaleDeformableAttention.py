@@ -328,11 +328,7 @@ def set_backward_deterministic(on: bool) -> bool:
 def backward_deterministic() -> bool:
     """Whether the bit-reproducible backward is on (the library holds the state; MVDETR_MSDA_BWD_DETERMINISTIC=1 sets its
     initial value)."""
-    lib = _lib.lib()
-    prev = lib.mvdetr_msda_set_backward_deterministic(1)
-    if not prev:
-        lib.mvdetr_msda_set_backward_deterministic(0)
-    return bool(prev)
+    return bool(_lib.lib().mvdetr_msda_get_backward_deterministic())
 
 
 def backward_deterministic_supported(B: int, S: int, M: int, D: int, L: int, Lq: int, P: int) -> bool:
