@@ -205,14 +205,15 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
         // one job, 48 bytes at a time, and merges in L2; holding all levels' results until the end cost 84 registers.
         constexpr int DEPTH = MVDETR_RS_DEPTH;
         float4 cbuf[DEPTH][8];
-        float tx_[DEPTH], ty_[DEPTH];
+        float twx_[DEPTH], twy_[DEPTH];                       // the far corner's weights of the taps in flight
         bool tin_[DEPTH];
         auto issue = [&](int l, int p, int s_) {
             const float lx = p == 0 ? la[l].x : p == 1 ? la[l].z : p == 2 ? lb[l].x : lb[l].z;
             const float ly = p == 0 ? la[l].y : p == 1 ? la[l].w : p == 2 ? lb[l].y : lb[l].w;
             const float x = lx * fW - 0.5f, y = ly * fH - 0.5f;
+            const float fx = floorf(x), fy = floorf(y);
             const bool in = fabsf(x - cx) < 0.5f * (WW - 1) && fabsf(y - cy) < 0.5f * (WH - 1);
-            const int ix = in ? (int)floorf(x) - ox : 0, iy = in ? (int)floorf(y) - oy : 0;
+            const int ix = in ? (int)fx - ox : 0, iy = in ? (int)fy - oy : 0;
             const float *p00 = vwin + l * NTOK * D + (iy * WW + ix) * D;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
@@ -222,13 +223,19 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
                 cbuf[s_][4 * k + 2] = *reinterpret_cast<const float4 *>(pk + WW * D);
                 cbuf[s_][4 * k + 3] = *reinterpret_cast<const float4 *>(pk + WW * D + D);
             }
-            tx_[s_] = x;
-            ty_[s_] = y;
+            twx_[s_] = x - fx;
+            twy_[s_] = y - fy;
             tin_[s_] = in;
+            // a tap outside its window (rare: a wave-uniform branch skips the image test): no gathers between the taps' LDS reads
+            // (round 5) -- it is noted, its gradients are zeros in the stream and are written again by the list walk behind the
+            // job's stores.  (A tap INSIDE the window needs no image test: the window is zero-padded outside the level, so the
+            // dots of a tap whose four corners are all outside are zero.)  Lanes without a cell carry cell 0's taps.
+            if (__builtin_amdgcn_ballot_w64(!in) != 0ull) {
+                if (!in && active && y > -1.f && x > -1.f && y < fH && x < fW) far_taps |= 1u << (l * P + p);
+            }
         };
         float ga[4], gx[4], gy[4];
         auto finish = [&](int l, int p, int s_) {
-            const float x = tx_[s_], y = ty_[s_];
             const float a = p == 0 ? wa[l].x : p == 1 ? wa[l].y : p == 2 ? wa[l].z : wa[l].w;
             f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
 #pragma unroll
@@ -238,22 +245,23 @@ __global__ __launch_bounds__(RS_THREADS, 2) void msda_bwd_sampling_resident(
                 q10 = dot4(g[k], cbuf[s_][4 * k + 2], q10);
                 q11 = dot4(g[k], cbuf[s_][4 * k + 3], q11);
             }
-            float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
-            d00 += neighbour(d00);                            // the other half of the head sits in the neighbouring lane
-            d01 += neighbour(d01);
-            d10 += neighbour(d10);
-            d11 += neighbour(d11);
-            const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
-            if (!tin_[s_]) {
-                // no gathers between the taps' LDS reads (round 5): the tap is noted, its gradients are zeros here and are
-                // written again by the list walk behind the job's stores
-                d00 = d01 = d10 = d11 = 0.f;
-                if (active && in_image) far_taps |= 1u << (l * P + p);      // (lanes without a cell carry cell 0's taps)
-            }
-            const float wx1 = x - floorf(x), wy1 = y - floorf(y), wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-            ga[p] = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
-            gx[p] = in_image ? fW * a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-            gy[p] = in_image ? fH * a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+            // this lane's half of the four dots -> its half of the three gradients (they are linear in the dots), THEN the sum
+            // with the other half of the head in the neighbouring lane: three cross-lane adds instead of four
+            const float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
+            const float wx1 = twx_[s_], wy1 = twy_[s_];
+            const float dx0 = d01 - d00, dx1 = d11 - d10, dy0 = d10 - d00, dy1 = d11 - d01;
+            const float top = d00 + wx1 * dx0, bot = d10 + wx1 * dx1;
+            float da = top + wy1 * (bot - top);               // = bilinear(d00 .. d11)
+            float gxv = dx0 + wy1 * (dx1 - dx0);
+            float gyv = dy0 + wx1 * (dy1 - dy0);
+            da += neighbour(da);
+            gxv += neighbour(gxv);
+            gyv += neighbour(gyv);
+            const bool in = tin_[s_];
+            const float ae = in ? a : 0.f;
+            ga[p] = in ? da : 0.f;
+            gx[p] = (fW * ae) * gxv;
+            gy[p] = (fH * ae) * gyv;
             if (p == P - 1 && active && sub == 0) {
                 *reinterpret_cast<float4 *>(grad_aw + e0 + l * P) = make_float4(ga[0], ga[1], ga[2], ga[3]);
                 *reinterpret_cast<float4 *>(grad_loc + (e0 + l * P) * 2) = make_float4(gx[0], gy[0], gx[1], gy[1]);
@@ -516,18 +524,28 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
                 };
                 // the three gradients of one tap from its four dots (public contract: grad_attn_weight, grad_sampling_loc; FUSED:
                 // logit, offsets -- a tap outside the image still has a logit: its weight takes part in the softmax)
+                // (takes THIS lane's half of the four dots: the gradients are linear in them, so the lane forms its half of
+                // (d a, d x, d y) and the two half-head lanes are summed afterwards -- three cross-lane adds instead of four)
                 auto tap_grads = [&](float d00, float d01, float d10, float d11, float wx1, float wy1, float a, bool in_image, float &ga_,
                                      float &gx_, float &gy_) {
-                    const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-                    const float da = in_image ? wy0 * (wx0 * d00 + wx1 * d01) + wy1 * (wx0 * d10 + wx1 * d11) : 0.f;
+                    const float dx0 = d01 - d00, dx1 = d11 - d10, dy0 = d10 - d00, dy1 = d11 - d01;
+                    const float top = d00 + wx1 * dx0, bot = d10 + wx1 * dx1;
+                    float da = top + wy1 * (bot - top);       // = bilinear(d00 .. d11)
+                    float gxv = dx0 + wy1 * (dx1 - dx0);
+                    float gyv = dy0 + wx1 * (dy1 - dy0);
+                    da += neighbour(da);                      // the other half of the head sits in the neighbouring lane
+                    gxv += neighbour(gxv);
+                    gyv += neighbour(gyv);
+                    da = in_image ? da : 0.f;
+                    const float ae = in_image ? a : 0.f;
                     if constexpr (FUSED) {
                         ga_ = a * (da - dq);
-                        gx_ = in_image ? a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-                        gy_ = in_image ? a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                        gx_ = ae * gxv;
+                        gy_ = ae * gyv;
                     } else {
                         ga_ = da;
-                        gx_ = in_image ? fW * a * ((d01 - d00) * wy0 + (d11 - d10) * wy1) : 0.f;
-                        gy_ = in_image ? fH * a * ((d10 - d00) * wx0 + (d11 - d01) * wx1) : 0.f;
+                        gx_ = (fW * ae) * gxv;
+                        gy_ = (fH * ae) * gyv;
                     }
                 };
                 float ga[4], gx[4], gy[4];
@@ -545,10 +563,6 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
                         q11 = dot4(g[k], cbuf[s_][4 * k + 3], q11);
                     }
                     float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
-                    d00 += neighbour(d00);                    // the other half of the head sits in the neighbouring lane
-                    d01 += neighbour(d01);
-                    d10 += neighbour(d10);
-                    d11 += neighbour(d11);
                     const bool in_image = y > -1.f && x > -1.f && y < fH && x < fW;
                     if (!in) {
                         d00 = d01 = d10 = d11 = 0.f;
@@ -603,11 +617,7 @@ __global__ __launch_bounds__(RS_THREADS, WPE) void msda_bwd_sampling_groups(
                     f2 q00 = {0.f, 0.f}, q01 = q00, q10 = q00, q11 = q00;
                     corners_of_footprint<NV>(vbatch + lsi[g0 + j] * row + sub * HALF, row, Wq, footprint_split(fy, wy1, fx, wx1, Hq, Wq), rot, g,
                                              q00, q01, q10, q11);
-                    float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
-                    d00 += neighbour(d00);
-                    d01 += neighbour(d01);
-                    d10 += neighbour(d10);
-                    d11 += neighbour(d11);
+                    const float d00 = hsum(q00), d01 = hsum(q01), d10 = hsum(q10), d11 = hsum(q11);
                     float ga1, gx1, gy1;
                     tap_grads(d00, d01, d10, d11, wx1, wy1, a, true, ga1, gx1, gy1);
                     if (sub == 0) {
