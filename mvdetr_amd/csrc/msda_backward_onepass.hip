@@ -43,9 +43,6 @@
 #ifndef MVDETR_SCATTER_WGS
 #define MVDETR_SCATTER_WGS 3     // workgroups per CU of the grad_value-only instantiation (register budget 512 / this per lane)
 #endif
-#ifndef MVDETR_OP_ENTRIES_AHEAD
-#define MVDETR_OP_ENTRIES_AHEAD 0
-#endif
 #ifndef MVDETR_OP_STAGGER
 #define MVDETR_OP_STAGGER 16      // x 64 cycles between the waves of a workgroup at the start of pass 1 (0 = none)
 #endif
@@ -561,13 +558,8 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
                     ga_b = reinterpret_cast<char *>(grad_aw + (int64_t)b * S * M * L * P);
                     loc_q = (unsigned)(M * L * P * 2) * 4u;
                     aw_q = (unsigned)(M * L * P) * 4u;
-#ifdef MVDETR_EXP_SAMELEVEL      // timing experiment (wrong results): every level job reads level 0's sampling lines
-                    loc_c = (unsigned)((head * L + 0) * P * 2 + pp * 2) * 4u;
-                    aw_c = (unsigned)((head * L + 0) * P + pp) * 4u;
-#else
                     loc_c = (unsigned)((head * L + l) * P * 2 + pp * 2) * 4u;
                     aw_c = (unsigned)((head * L + l) * P + pp) * 4u;
-#endif
                 }
 
                 unsigned cam_q[CAMS];                             // first token of the pass's cameras (uniform)
@@ -700,21 +692,14 @@ __global__ __launch_bounds__(Cfg::THREADS, Cfg::WPS) void msda_bwd_onepass(
 #pragma unroll
                                 for (int h = 0; h < 4; ++h) V[bt][h] = *reinterpret_cast<const float2 *>(lds_raw + of[h] + pair_off);
                             };
-#if MVDETR_OP_ENTRIES_AHEAD
-                            // (experiment: the step's entries all requested up front -- 4 CH registers more, no LDS round trip
-                            // inside the stream)
-#pragma unroll
-                            for (int bt = 0; bt < CH; ++bt) read_entries(bt);
-#else
+                            // (all of a step's entries requested up front -- no LDS round trip inside the stream -- was measured in
+                            // round 6: the same time at three workgroups per CU, where it spills, and slower at two)
                             read_entries(0);
-#endif
 #pragma unroll
                             for (int bt = 0; bt < CH; ++bt) {
                                 if (NC == 0 && c0 + bt >= L) break;             // (uniform)
                                 if constexpr (DOTS) read_values(bt);
-#if !MVDETR_OP_ENTRIES_AHEAD
                                 if (bt + 1 < CH) read_entries(bt + 1);
-#endif
                                 const float wg[4] = {E[bt][0].x, E[bt][0].z, E[bt][1].x, E[bt][1].z};
                                 const int of[4] = {__float_as_int(E[bt][0].y), __float_as_int(E[bt][0].w), __float_as_int(E[bt][1].y), __float_as_int(E[bt][1].w)};
 #pragma unroll
